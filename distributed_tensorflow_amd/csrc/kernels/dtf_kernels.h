@@ -1,0 +1,101 @@
+// C ABI of libdtf_kernels.so (gfx950 only).  Mirrored field-for-field by the
+// ctypes structures in distributed_tensorflow_amd/ops/_lib.py.
+#pragma once
+#include "dtf_common.h"
+
+// ---------------------------------------------------------------------------
+// Device-resident step bookkeeping.  The training step never returns to the
+// host: the last kernel of a step bumps the counters, appends one log record
+// and selects the rows of the next mini-batch, so that n steps can be replayed
+// from one hipGraph.  (Replaces the per-step global_step fetch, loss fetch and
+// feed upload of /root/reference/distributed.py:137-149.)
+// ---------------------------------------------------------------------------
+struct DtfTailArgs {
+  int* state;               // [0] = global_step (starts at 1, distributed.py:65), [1] = local_step
+  int* log;                 // log_cap records of 4 x int32: {loss bits, correct, post_correct(prev batch), global_step fetched}
+  const float* loss_part;   // per-workgroup partial loss sums written by the head kernel
+  const int* correct_part;  // per-workgroup correct counts on the training rows
+  const int* post_part;     // per-workgroup correct counts on the accuracy-only rows
+  const int* ridx_cur;      // [2*B] dataset rows of the step that is finishing ([0,B) = its training batch)
+  int* ridx_next;           // [2*B] written for the next step: [0,B) = new batch, [B,2B) = the batch just trained on
+                            // (accuracy-only rows).  Must not alias ridx_cur: other workgroups of the same
+                            // launch are still reading it.
+  const int* perm;          // [2][n_train] double-buffered epoch permutations (buffer = epoch & 1)
+  int nparts;
+  int log_cap;
+  int B;
+  int n_train;
+  int gs_inc;               // global_step increment per step
+  int enable;               // 0 = no tail work at all
+  float inv_b;              // 1 / B, turns the loss sum into the mean
+  int pad_;
+};
+
+struct DtfSmallGemmArgs {
+  const float* A;           // [M, K] row-major, leading dim lda
+  const int* a_rows;        // optional gather: logical row i reads A row a_rows[i]
+  const float* B;           // NN: [K, N] (ldb); NT: [N, K] (ldb)
+  const float* bias;        // optional [N]
+  const float* mask;        // optional [M, N]: output kept where mask > 0 (ReLU backward)
+  float* C;                 // [M, N] (ldc)
+  int M, N, K;
+  int lda, ldb, ldc, ldmask;
+  int relu;
+  int b_transposed;
+};
+
+#define DTF_MAX_WGRAD_PROBLEMS 8
+struct DtfWgradProblem {
+  const float* X;           // [Kb, Mo] activations (rows optionally gathered through x_rows)
+  const int* x_rows;
+  const float* dY;          // [Kb, N]
+  float* dW;                // [Mo, N] gradient out (mode 0) / unused (mode 1)
+  float* db;                // [N]
+  float* W;                 // [Mo, N] parameter updated in place (mode 1)
+  float* b;                 // [N]
+  int Mo, N, Kb;
+  int ldx, ldy, ldw;
+  int tile_start;           // first linear tile id of this problem
+  int tiles_n;
+};
+
+struct DtfWgradArgs {
+  DtfWgradProblem prob[DTF_MAX_WGRAD_PROBLEMS];
+  int nprob;
+  int total_tiles;
+  int mode;                 // 0: store gradients, 1: theta -= lr * grad fused in the epilogue
+  float lr;
+  DtfTailArgs tail;
+};
+
+struct DtfHeadArgs {
+  const float* Hact;        // [M_total, Hd] last hidden activation (post-ReLU)
+  const float* W2;          // [Hd, C]
+  const float* b2;          // [C]
+  const float* labels;      // [rows, C] one-hot / soft labels
+  const int* rows;          // optional gather of label rows
+  float* dz2;               // [M_train, 16] gradient wrt logits, zero padded to 16 columns
+  float* dz1;               // [M_train, Hd] gradient wrt the hidden pre-activation (ReLU mask applied)
+  float* probs;             // optional [M_total, C] softmax output y
+  float* loss_part;
+  int* correct_part;
+  int* post_part;
+  int M_total, M_train, Hd, C;
+  int ldh, ld_dz1;
+  int loss_mode;            // 0: reference (softmax applied twice, distributed.py:81+86), 1: standard xent on logits
+  float inv_b;
+};
+
+DTF_EXPORT int dtf_small_gemm(const DtfSmallGemmArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_wgrad_grouped(const DtfWgradArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_head(const DtfHeadArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_step_tail(const DtfTailArgs* a, int init_only, hipStream_t s);
+
+// flat fused optimizers (shard updates)
+DTF_EXPORT int dtf_sgd_apply(float* param, const float* grad, int64_t n, float lr, float grad_scale, hipStream_t s);
+DTF_EXPORT int dtf_adam_apply(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float grad_scale, const int* step_ptr, int step_offset,
+                              hipStream_t s);
+DTF_EXPORT int dtf_truncated_normal(float* out, int64_t n, float stddev, uint64_t seed, uint64_t stream_id, hipStream_t s);
+DTF_EXPORT int dtf_accumulate(float* dst, const float* src, int64_t n, float alpha, float beta, hipStream_t s);
+DTF_EXPORT int dtf_kernels_abi_version();

@@ -1,0 +1,172 @@
+// Flat fused shard updates and parameter initialisation.
+//
+// The parameter-server role of /root/reference/distributed.py (variables on
+// /job:ps, ApplyGradientDescent executed there, :60-64, :89, :102) becomes: each
+// rank owns a contiguous slice of one flat fp32 parameter buffer in HBM and
+// applies the optimizer to that slice with one launch.  These kernels are pure
+// streaming (16 B per lane, grid-stride, <= 2048 workgroups), i.e. HBM-bound.
+#include "dtf_kernels.h"
+
+static inline int stream_grid(int64_t nvec, int block) {
+  int64_t g = (nvec + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (int)g;
+}
+
+// theta -= lr * scale * g        (scale = 1/R turns a reduce-scatter sum into the SyncReplicas mean)
+__global__ __launch_bounds__(256) void sgd_apply_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n,
+                                                        float step) {
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    pv.x -= step * gv.x; pv.y -= step * gv.y; pv.z -= step * gv.z; pv.w -= step * gv.w;
+    reinterpret_cast<float4*>(p)[i] = pv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (nvec << 2) + threadIdx.x;
+    p[i] -= step * g[i];
+  }
+}
+
+DTF_EXPORT int dtf_sgd_apply(float* param, const float* grad, int64_t n, float lr, float grad_scale, hipStream_t s) {
+  if (!param || !grad) return DTF_ERR_ARG;
+  if (n <= 0) return DTF_ERR_SHAPE;
+  if (!dtf_aligned16(param) || !dtf_aligned16(grad)) return DTF_ERR_ALIGN;
+  hipLaunchKernelGGL(sgd_apply_kernel, dim3(stream_grid(n >> 2, 256)), dim3(256), 0, s, param, grad, n, lr * grad_scale);
+  return dtf_check_launch();
+}
+
+// Adam with bias correction; the step number is read from device memory so the
+// launch can sit inside a replayed hipGraph.
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps_t) {
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  p -= lr_t * m / (sqrtf(v) + eps_t);
+}
+
+__global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                         float b1, float b2, float eps, float gscale,
+                                                         const int* __restrict__ step_ptr, int step_offset) {
+  // t counts applied updates starting at 1
+  const int t = (step_ptr ? *step_ptr : 0) + step_offset;
+  const float bc1 = 1.f - powf(b1, (float)t);
+  const float bc2 = 1.f - powf(b2, (float)t);
+  // TF-style folding: lr_t = lr * sqrt(1-b2^t)/(1-b1^t), epsilon applied to sqrt(v) un-corrected is
+  // "epsilon hat"; we keep the textbook form by scaling eps with sqrt(bc2).
+  const float sq = sqrtf(bc2);
+  const float lr_t = lr * sq / bc1;
+  const float eps_t = eps * sq;
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    adam_one(pv.x, gv.x * gscale, mv.x, vv.x, lr_t, b1, b2, eps_t);
+    adam_one(pv.y, gv.y * gscale, mv.y, vv.y, lr_t, b1, b2, eps_t);
+    adam_one(pv.z, gv.z * gscale, mv.z, vv.z, lr_t, b1, b2, eps_t);
+    adam_one(pv.w, gv.w * gscale, mv.w, vv.w, lr_t, b1, b2, eps_t);
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (nvec << 2) + threadIdx.x;
+    adam_one(p[i], g[i] * gscale, m[i], v[i], lr_t, b1, b2, eps_t);
+  }
+}
+
+DTF_EXPORT int dtf_adam_apply(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float grad_scale, const int* step_ptr, int step_offset,
+                              hipStream_t s) {
+  if (!param || !grad || !m || !v) return DTF_ERR_ARG;
+  if (n <= 0) return DTF_ERR_SHAPE;
+  if (!dtf_aligned16(param) || !dtf_aligned16(grad) || !dtf_aligned16(m) || !dtf_aligned16(v)) return DTF_ERR_ALIGN;
+  hipLaunchKernelGGL(adam_apply_kernel, dim3(stream_grid(n >> 2, 256)), dim3(256), 0, s, param, grad, m, v, n, lr, beta1,
+                     beta2, eps, grad_scale, step_ptr, step_offset);
+  return dtf_check_launch();
+}
+
+// dst = alpha * dst + beta * src   (gradient accumulation over several rounds, R > num_workers)
+__global__ __launch_bounds__(256) void accumulate_kernel(float* __restrict__ d, const float* __restrict__ s, int64_t n,
+                                                         float alpha, float beta) {
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    float4 dv = reinterpret_cast<float4*>(d)[i];
+    const float4 sv = reinterpret_cast<const float4*>(s)[i];
+    dv.x = alpha * dv.x + beta * sv.x; dv.y = alpha * dv.y + beta * sv.y;
+    dv.z = alpha * dv.z + beta * sv.z; dv.w = alpha * dv.w + beta * sv.w;
+    reinterpret_cast<float4*>(d)[i] = dv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (nvec << 2) + threadIdx.x;
+    d[i] = alpha * d[i] + beta * s[i];
+  }
+}
+
+DTF_EXPORT int dtf_accumulate(float* dst, const float* src, int64_t n, float alpha, float beta, hipStream_t s) {
+  if (!dst || !src) return DTF_ERR_ARG;
+  if (n <= 0) return DTF_ERR_SHAPE;
+  if (!dtf_aligned16(dst) || !dtf_aligned16(src)) return DTF_ERR_ALIGN;
+  hipLaunchKernelGGL(accumulate_kernel, dim3(stream_grid(n >> 2, 256)), dim3(256), 0, s, dst, src, n, alpha, beta);
+  return dtf_check_launch();
+}
+
+// --------------------------------------------------------------------------------------
+// truncated normal initialiser (tf.truncated_normal, distributed.py:67-72): N(0, stddev)
+// re-sampled until |v| <= 2 stddev.  Counter-based Philox4x32-10, one counter block per
+// (element, attempt) so the result does not depend on the launch geometry.
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ __launch_bounds__(256) void truncated_normal_kernel(float* __restrict__ out, int64_t n, float stddev,
+                                                               uint64_t seed, uint64_t stream_id) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float val = 0.f;
+    bool done = false;
+    for (uint32_t attempt = 0; attempt < 64 && !done; ++attempt) {
+      uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), attempt, (uint32_t)stream_id};
+      philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+      // two Box-Muller pairs per counter block
+      const float u0 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u1 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u2 = ((float)(c[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u3 = ((float)(c[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+      const float z[4] = {r0 * cosf(6.28318530718f * u1), r0 * sinf(6.28318530718f * u1),
+                          r1 * cosf(6.28318530718f * u3), r1 * sinf(6.28318530718f * u3)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!done && fabsf(z[j]) <= 2.f) { val = z[j]; done = true; }
+    }
+    out[i] = val * stddev;
+  }
+}
+
+DTF_EXPORT int dtf_truncated_normal(float* out, int64_t n, float stddev, uint64_t seed, uint64_t stream_id, hipStream_t s) {
+  if (!out) return DTF_ERR_ARG;
+  if (n <= 0) return DTF_ERR_SHAPE;
+  hipLaunchKernelGGL(truncated_normal_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, out, n, stddev, seed, stream_id);
+  return dtf_check_launch();
+}
+
+DTF_EXPORT int dtf_kernels_abi_version() { return 1; }

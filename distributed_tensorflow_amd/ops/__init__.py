@@ -1,0 +1,307 @@
+"""Op layer: every op has one HIP implementation (GPU tensors, gfx950 kernels in
+``csrc/kernels``) and one plain PyTorch statement (CPU tensors, ``reference.py``).
+
+GPU tensors always go to the HIP kernels; if the kernel library is missing the
+call raises instead of falling back.  All GPU entry points write into
+caller-provided output buffers so that a whole training step allocates nothing
+and can be captured into a hipGraph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, reference
+from .reference import LOSS_REFERENCE, LOSS_STANDARD  # noqa: F401
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+def _i32c(t, name):
+    if t.dtype != torch.int32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous int32 tensor")
+    return t
+
+
+def _same_device(*ts):
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+# --------------------------------------------------------------------------- linear
+def linear_fwd(x, w, b=None, relu=False, rows=None, out=None, m=None):
+    """``out[:m] = act(x[rows[:m]] @ w + b)``; K1 of the reference graph (distributed.py:78-79)."""
+    K, N = w.shape
+    M = m if m is not None else (rows.shape[0] if rows is not None else x.shape[0])
+    if x.shape[1] != K:
+        raise ValueError(f"linear_fwd: x has {x.shape[1]} columns, w has {K} rows")
+    if not x.is_cuda:
+        y = reference.linear_fwd(x if rows is not None else x[:M], w, b, relu, rows[:M] if rows is not None else None)
+        if out is None:
+            return y
+        out[:M].copy_(y)
+        return out
+    _same_device(x, w, b, rows, out)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if out.shape[0] < M or out.shape[1] != N:
+        raise ValueError(f"linear_fwd: out {tuple(out.shape)} cannot hold [{M},{N}]")
+    if rows is not None and rows.shape[0] < M:
+        raise ValueError("linear_fwd: rows shorter than m")
+    if rows is None and x.shape[0] < M:
+        raise ValueError("linear_fwd: x has fewer rows than m")
+    a = _lib.SmallGemmArgs(A=_f32c(x, "x").data_ptr(), a_rows=_lib.ptr(None if rows is None else _i32c(rows, "rows")),
+                           B=_f32c(w, "w").data_ptr(), bias=_lib.ptr(None if b is None else _f32c(b, "b")), mask=None,
+                           C=_f32c(out, "out").data_ptr(), M=M, N=N, K=K, lda=x.stride(0), ldb=w.stride(0),
+                           ldc=out.stride(0), ldmask=0, relu=int(bool(relu)), b_transposed=0)
+    if b is not None and b.numel() != N:
+        raise ValueError("linear_fwd: bias size mismatch")
+    _lib.check(_lib.kernels().dtf_small_gemm(C.byref(a), _lib.stream_handle()), "linear_fwd")
+    return out
+
+
+def linear_bwd_data(dy, w, act=None, out=None, m=None):
+    """``out[:m] = (dy[:m] @ w^T) * (act > 0)``; MatMul grad + ReluGrad (K7)."""
+    K, N = w.shape          # w is the forward weight [in, out]; dy is [M, out]
+    M = m if m is not None else dy.shape[0]
+    if dy.shape[1] != N:
+        raise ValueError("linear_bwd_data: dy/w shape mismatch")
+    if not dy.is_cuda:
+        r = reference.linear_bwd_data(dy[:M], w, None if act is None else act[:M])
+        if out is None:
+            return r
+        out[:M].copy_(r)
+        return out
+    _same_device(dy, w, act, out)
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    if out.shape[0] < M or out.shape[1] != K or dy.shape[0] < M:
+        raise ValueError("linear_bwd_data: bad out/dy shape")
+    if act is not None and (act.shape[0] < M or act.shape[1] != K):
+        raise ValueError("linear_bwd_data: bad act shape")
+    a = _lib.SmallGemmArgs(A=_f32c(dy, "dy").data_ptr(), a_rows=None, B=_f32c(w, "w").data_ptr(), bias=None,
+                           mask=_lib.ptr(None if act is None else _f32c(act, "act")), C=_f32c(out, "out").data_ptr(),
+                           M=M, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0),
+                           ldmask=0 if act is None else act.stride(0), relu=0, b_transposed=1)
+    _lib.check(_lib.kernels().dtf_small_gemm(C.byref(a), _lib.stream_handle()), "linear_bwd_data")
+    return out
+
+
+class WgradItem:
+    """One ``dW = x[rows]^T @ dy``, ``db = colsum(dy)`` problem of a grouped launch."""
+
+    def __init__(self, x, dy, kb, n=None, rows=None, dw=None, db=None, w=None, b=None):
+        self.x, self.dy, self.kb, self.rows = x, dy, kb, rows
+        self.n = n if n is not None else dy.shape[1]
+        self.dw, self.db, self.w, self.b = dw, db, w, b
+
+
+def make_tail(state, log=None, loss_part=None, correct_part=None, post_part=None, ridx_cur=None, ridx_next=None,
+              perm=None, batch=0, n_train=0, gs_inc=1, enable=True):
+    nparts = 0 if loss_part is None else loss_part.numel()
+    return _lib.TailArgs(state=_lib.ptr(state), log=_lib.ptr(log), loss_part=_lib.ptr(loss_part),
+                         correct_part=_lib.ptr(correct_part), post_part=_lib.ptr(post_part), ridx_cur=_lib.ptr(ridx_cur),
+                         ridx_next=_lib.ptr(ridx_next), perm=_lib.ptr(perm), nparts=nparts,
+                         log_cap=0 if log is None else log.shape[0], B=batch, n_train=n_train, gs_inc=gs_inc,
+                         enable=int(enable), inv_b=(1.0 / batch) if batch else 0.0, pad_=0)
+
+
+def build_wgrad_args(items, lr=None, tail=None):
+    """Pack a grouped weight-gradient launch.  ``lr`` given => parameters are updated in the
+    epilogue (theta -= lr*grad, world size 1 + SGD); otherwise gradients are stored."""
+    if not 0 < len(items) <= _lib.MAX_WGRAD_PROBLEMS:
+        raise ValueError("wgrad_grouped: between 1 and 8 problems per launch")
+    args = _lib.WgradArgs()
+    tiles = 0
+    fused = lr is not None
+    for i, it in enumerate(items):
+        mo = it.x.shape[1]
+        n = it.n
+        tgt_w = it.w if fused else it.dw
+        tgt_b = it.b if fused else it.db
+        if tgt_w is None or tgt_b is None:
+            raise ValueError("wgrad_grouped: missing output tensors")
+        if tuple(tgt_w.shape) != (mo, n) or tgt_b.numel() != n:
+            raise ValueError(f"wgrad_grouped: output shape {tuple(tgt_w.shape)} != ({mo},{n})")
+        if it.dy.shape[0] < it.kb or it.dy.shape[1] < n:
+            raise ValueError("wgrad_grouped: dy too small")
+        if it.rows is None and it.x.shape[0] < it.kb:
+            raise ValueError("wgrad_grouped: x too small")
+        if it.rows is not None and it.rows.numel() < it.kb:
+            raise ValueError("wgrad_grouped: rows too short")
+        p = args.prob[i]
+        p.X = _f32c(it.x, "x").data_ptr()
+        p.x_rows = _lib.ptr(None if it.rows is None else _i32c(it.rows, "rows"))
+        p.dY = _f32c(it.dy, "dy").data_ptr()
+        p.dW = _lib.ptr(it.dw)
+        p.db = _lib.ptr(it.db)
+        p.W = _lib.ptr(it.w)
+        p.b = _lib.ptr(it.b)
+        p.Mo, p.N, p.Kb = mo, n, it.kb
+        p.ldx, p.ldy, p.ldw = it.x.stride(0), it.dy.stride(0), tgt_w.stride(0)
+        p.tile_start = tiles
+        p.tiles_n = (n + 15) // 16
+        tiles += p.tiles_n * ((mo + 15) // 16)
+    args.nprob = len(items)
+    args.total_tiles = tiles
+    args.mode = 1 if fused else 0
+    args.lr = float(lr) if fused else 0.0
+    if tail is not None:
+        args.tail = tail
+    else:
+        args.tail.enable = 0
+    return args
+
+
+def wgrad_grouped(items, lr=None, tail=None, args=None):
+    """All weight/bias gradients of the step in one launch (K6, K8, K9; optionally K10+K11 fused)."""
+    dev = items[0].x.device if items else None
+    if dev is not None and dev.type != "cuda":
+        for it in items:
+            dw, db = reference.wgrad(it.x if it.rows is not None else it.x[:it.kb], it.dy[:it.kb, :it.n],
+                                     None if it.rows is None else it.rows[:it.kb])
+            if lr is not None:
+                it.w.sub_(lr * dw)
+                it.b.sub_(lr * db)
+            else:
+                it.dw.copy_(dw)
+                it.db.copy_(db)
+        return None
+    if args is None:
+        args = build_wgrad_args(items, lr, tail)
+    _lib.check(_lib.kernels().dtf_wgrad_grouped(C.byref(args), _lib.stream_handle()), "wgrad_grouped")
+    return args
+
+
+# --------------------------------------------------------------------------- head
+def build_head_args(hact, w2, b2, labels, m_total, m_train, loss_mode, rows=None, dz2=None, dz1=None, probs=None,
+                    loss_part=None, correct_part=None, post_part=None):
+    hd, c = w2.shape
+    if c > 16:
+        raise ValueError("head: at most 16 classes")
+    nblk = (m_total + 15) // 16
+    for name, t in (("loss_part", loss_part), ("correct_part", correct_part), ("post_part", post_part)):
+        if t is not None and t.numel() < nblk:
+            raise ValueError(f"head: {name} needs {nblk} entries")
+    if hact.shape[0] < m_total or hact.shape[1] != hd:
+        raise ValueError("head: hact shape mismatch")
+    if rows is not None and rows.numel() < m_total:
+        raise ValueError("head: rows too short")
+    if rows is None and labels.shape[0] < m_total:
+        raise ValueError("head: labels too short")
+    if labels.shape[1] != c:
+        raise ValueError("head: labels width mismatch")
+    if m_train > 0:
+        if dz2 is not None and (dz2.shape[0] < m_train or dz2.shape[1] != 16 or not dz2.is_contiguous()):
+            raise ValueError("head: dz2 must be [>=m_train, 16] contiguous")
+        if dz1 is not None and (dz1.shape[0] < m_train or dz1.shape[1] != hd):
+            raise ValueError("head: dz1 shape mismatch")
+    if probs is not None and (probs.shape[0] < m_total or probs.shape[1] != c or not probs.is_contiguous()):
+        raise ValueError("head: probs shape mismatch")
+    return _lib.HeadArgs(Hact=_f32c(hact, "hact").data_ptr(), W2=_f32c(w2, "w2").data_ptr(), b2=_f32c(b2, "b2").data_ptr(),
+                         labels=_f32c(labels, "labels").data_ptr(),
+                         rows=_lib.ptr(None if rows is None else _i32c(rows, "rows")), dz2=_lib.ptr(dz2),
+                         dz1=_lib.ptr(dz1), probs=_lib.ptr(probs), loss_part=_lib.ptr(loss_part),
+                         correct_part=_lib.ptr(correct_part), post_part=_lib.ptr(post_part), M_total=m_total,
+                         M_train=m_train, Hd=hd, C=c, ldh=hact.stride(0), ld_dz1=0 if dz1 is None else dz1.stride(0),
+                         loss_mode=loss_mode, inv_b=(1.0 / m_train) if m_train else 0.0)
+
+
+def head(hact, w2, b2, labels, m_total, m_train, loss_mode=LOSS_REFERENCE, rows=None, dz2=None, dz1=None, probs=None,
+         loss_part=None, correct_part=None, post_part=None, args=None):
+    """Fused last layer: logits, softmax, (double-)softmax cross-entropy, accuracy counts,
+    dz2 and dz1 (K2-K5 + K7 of the reference graph, distributed.py:81-87)."""
+    if not hact.is_cuda:
+        r = reference.head(hact[:m_total], w2, b2, labels, m_train, loss_mode, rows, want_dz1=dz1 is not None)
+        if probs is not None:
+            probs[:m_total].copy_(r["probs"])
+        if m_train > 0:
+            if dz2 is not None:
+                dz2[:m_train].zero_()
+                dz2[:m_train, :w2.shape[1]].copy_(r["dz2"])
+            if dz1 is not None:
+                dz1[:m_train].copy_(r["dz1"])
+        for t, v in ((loss_part, r["loss_sum"]), (correct_part, r["correct"]), (post_part, r["post_correct"])):
+            if t is not None:
+                t.zero_()
+                t[0] = v
+        return r
+    if args is None:
+        args = build_head_args(hact, w2, b2, labels, m_total, m_train, loss_mode, rows, dz2, dz1, probs, loss_part,
+                               correct_part, post_part)
+    _lib.check(_lib.kernels().dtf_head(C.byref(args), _lib.stream_handle()), "head")
+    return args
+
+
+def step_tail(tail, init_only=False):
+    _lib.check(_lib.kernels().dtf_step_tail(C.byref(tail), int(init_only), _lib.stream_handle()), "step_tail")
+
+
+# --------------------------------------------------------------------------- optimizers / init
+def sgd_apply(param, grad, lr, grad_scale=1.0):
+    """``param -= lr * grad_scale * grad`` over a flat shard (K10; ApplyGradientDescent, distributed.py:89)."""
+    if param.numel() != grad.numel():
+        raise ValueError("sgd_apply: size mismatch")
+    if not param.is_cuda:
+        return reference.sgd_apply(param, grad, lr, grad_scale)
+    _same_device(param, grad)
+    _lib.check(_lib.kernels().dtf_sgd_apply(_f32c(param, "param").data_ptr(), _f32c(grad, "grad").data_ptr(), param.numel(),
+                                            lr, grad_scale, _lib.stream_handle()), "sgd_apply")
+    return param
+
+
+def adam_apply(param, grad, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, step=None, step_tensor=None,
+               step_offset=0):
+    """Fused Adam over a flat shard.  The step number is ``step`` (host int) or
+    ``step_tensor[0] + step_offset`` read on the device (hipGraph-replayable)."""
+    n = param.numel()
+    if not (grad.numel() == m.numel() == v.numel() == n):
+        raise ValueError("adam_apply: size mismatch")
+    if not param.is_cuda:
+        t = step if step is not None else int(step_tensor[0].item()) + step_offset
+        return reference.adam_apply(param, grad, m, v, lr, beta1, beta2, eps, grad_scale, t)
+    _same_device(param, grad, m, v, step_tensor)
+    if step_tensor is None:
+        sp, off = None, int(step)
+    else:
+        sp, off = _i32c(step_tensor, "step_tensor").data_ptr(), step_offset
+    _lib.check(_lib.kernels().dtf_adam_apply(_f32c(param, "param").data_ptr(), _f32c(grad, "grad").data_ptr(),
+                                             _f32c(m, "m").data_ptr(), _f32c(v, "v").data_ptr(), n, lr, beta1, beta2, eps,
+                                             grad_scale, sp, off, _lib.stream_handle()), "adam_apply")
+    return param
+
+
+def accumulate(dst, src, alpha=1.0, beta=1.0):
+    """``dst = alpha*dst + beta*src`` (gradient accumulation across rounds)."""
+    if dst.numel() != src.numel():
+        raise ValueError("accumulate: size mismatch")
+    if not dst.is_cuda:
+        dst.mul_(alpha).add_(src, alpha=beta)
+        return dst
+    _lib.check(_lib.kernels().dtf_accumulate(_f32c(dst, "dst").data_ptr(), _f32c(src, "src").data_ptr(), dst.numel(), alpha,
+                                             beta, _lib.stream_handle()), "accumulate")
+    return dst
+
+
+def truncated_normal_(out, stddev, seed, stream_id=0):
+    """Fill ``out`` with N(0, stddev) truncated at two standard deviations (distributed.py:67-72)."""
+    if not out.is_cuda:
+        g = torch.Generator(device="cpu")
+        g.manual_seed((int(seed) * 1000003 + int(stream_id)) % (2 ** 63))
+        out.copy_(reference.truncated_normal(tuple(out.shape), stddev, g))
+        return out
+    _lib.check(_lib.kernels().dtf_truncated_normal(_f32c(out, "out").data_ptr(), out.numel(), stddev, int(seed),
+                                                   int(stream_id), _lib.stream_handle()), "truncated_normal")
+    return out

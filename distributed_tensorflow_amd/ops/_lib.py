@@ -1,0 +1,139 @@
+"""ctypes bindings of the in-tree native libraries.
+
+``libdtf_kernels.so`` holds the gfx950 HIP kernels, ``libdtf_runtime.so`` the
+host runtime (checkpoint bundle I/O, data pipeline, parameter-server service).
+Both are built by ``csrc/Makefile`` into ``distributed_tensorflow_amd/lib``.
+
+The kernel library is only loaded when a GPU is visible.  On a GPU box a
+missing library is an error (never a silent fallback to eager PyTorch): see
+:func:`kernels`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib")
+_lock = threading.Lock()
+_kernels = None
+_runtime = None
+
+ERR_NAMES = {1: "operand shapes do not match the kernel's grid assumptions", 2: "pointer/leading dimension not 16-byte aligned",
+             3: "hip launch failed", 4: "null pointer or unsupported option"}
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class TailArgs(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("log", C.c_void_p), ("loss_part", C.c_void_p), ("correct_part", C.c_void_p),
+                ("post_part", C.c_void_p), ("ridx_cur", C.c_void_p), ("ridx_next", C.c_void_p), ("perm", C.c_void_p),
+                ("nparts", C.c_int), ("log_cap", C.c_int), ("B", C.c_int), ("n_train", C.c_int), ("gs_inc", C.c_int),
+                ("enable", C.c_int), ("inv_b", C.c_float), ("pad_", C.c_int)]
+
+
+class SmallGemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("a_rows", C.c_void_p), ("B", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p),
+                ("C", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int),
+                ("ldc", C.c_int), ("ldmask", C.c_int), ("relu", C.c_int), ("b_transposed", C.c_int)]
+
+
+MAX_WGRAD_PROBLEMS = 8
+
+
+class WgradProblem(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("x_rows", C.c_void_p), ("dY", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p),
+                ("W", C.c_void_p), ("b", C.c_void_p), ("Mo", C.c_int), ("N", C.c_int), ("Kb", C.c_int), ("ldx", C.c_int),
+                ("ldy", C.c_int), ("ldw", C.c_int), ("tile_start", C.c_int), ("tiles_n", C.c_int)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("prob", WgradProblem * MAX_WGRAD_PROBLEMS), ("nprob", C.c_int), ("total_tiles", C.c_int),
+                ("mode", C.c_int), ("lr", C.c_float), ("tail", TailArgs)]
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [("Hact", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("labels", C.c_void_p), ("rows", C.c_void_p),
+                ("dz2", C.c_void_p), ("dz1", C.c_void_p), ("probs", C.c_void_p), ("loss_part", C.c_void_p),
+                ("correct_part", C.c_void_p), ("post_part", C.c_void_p), ("M_total", C.c_int), ("M_train", C.c_int),
+                ("Hd", C.c_int), ("C", C.c_int), ("ldh", C.c_int), ("ld_dz1", C.c_int), ("loss_mode", C.c_int),
+                ("inv_b", C.c_float)]
+
+
+def lib_path(name: str) -> str:
+    return os.path.join(_LIB_DIR, name)
+
+
+def _declare_kernels(lib):
+    vp, i32, i64, f32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+    lib.dtf_small_gemm.argtypes = [C.POINTER(SmallGemmArgs), vp]
+    lib.dtf_wgrad_grouped.argtypes = [C.POINTER(WgradArgs), vp]
+    lib.dtf_head.argtypes = [C.POINTER(HeadArgs), vp]
+    lib.dtf_step_tail.argtypes = [C.POINTER(TailArgs), i32, vp]
+    lib.dtf_sgd_apply.argtypes = [vp, vp, i64, f32, f32, vp]
+    lib.dtf_adam_apply.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]
+    lib.dtf_truncated_normal.argtypes = [vp, i64, f32, u64, u64, vp]
+    lib.dtf_accumulate.argtypes = [vp, vp, i64, f32, f32, vp]
+    for name in ("dtf_small_gemm", "dtf_wgrad_grouped", "dtf_head", "dtf_step_tail", "dtf_sgd_apply", "dtf_adam_apply",
+                 "dtf_truncated_normal", "dtf_accumulate", "dtf_kernels_abi_version"):
+        getattr(lib, name).restype = i32
+
+
+def kernels():
+    """Return the HIP kernel library, loading it on first use.
+
+    Raises :class:`NativeLibraryMissing` if the ``.so`` has not been built; the
+    callers in :mod:`distributed_tensorflow_amd.ops` never substitute eager
+    PyTorch for a missing kernel on a GPU tensor.
+    """
+    global _kernels
+    if _kernels is None:
+        with _lock:
+            if _kernels is None:
+                path = lib_path("libdtf_kernels.so")
+                if not os.path.exists(path):
+                    raise NativeLibraryMissing(
+                        f"{path} not found: build it with `make -C distributed_tensorflow_amd/csrc` "
+                        "before using the GPU path")
+                lib = C.CDLL(path)
+                _declare_kernels(lib)
+                _kernels = lib
+    return _kernels
+
+
+def kernels_available() -> bool:
+    return os.path.exists(lib_path("libdtf_kernels.so"))
+
+
+def runtime():
+    """Return the host runtime library (pure C++, no GPU needed)."""
+    global _runtime
+    if _runtime is None:
+        with _lock:
+            if _runtime is None:
+                path = lib_path("libdtf_runtime.so")
+                if not os.path.exists(path):
+                    raise NativeLibraryMissing(f"{path} not found: build it with `make -C distributed_tensorflow_amd/csrc`")
+                _runtime = C.CDLL(path)
+    return _runtime
+
+
+def runtime_available() -> bool:
+    return os.path.exists(lib_path("libdtf_runtime.so"))
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what}: native launcher refused the call ({ERR_NAMES.get(code, code)})")
+
+
+def stream_handle() -> int:
+    """hipStream_t of PyTorch's current stream (also valid while it is being captured)."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
