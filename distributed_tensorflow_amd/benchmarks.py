@@ -1,0 +1,107 @@
+"""Benchmark driver behind ``bench.py`` (the JSON contract is documented there)."""
+from __future__ import annotations
+
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .data import mnist
+from .data.device_dataset import DeviceDataset
+from .models.mlp import MLPProgram, build_mlp_state
+from .parallel import comm
+from .parallel.sync_replicas import SyncReplicasEngine
+
+METRIC = "examples/sec (whole node)"
+
+
+def _setup_distributed(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.cpu or not torch.cuda.is_available():
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    if world > 1:
+        comm.init_from_env(device)
+    return rank, world, device
+
+
+def _sync_all(device, world):
+    if world > 1:
+        if device.type == "cuda":
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def _max_over_ranks(value: float, device, world) -> float:
+    if world == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device.type == "cuda" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def bench_mlp_sync(args, rank, world, device, wide: bool = False):
+    batch = args.batch_size or (100 if not wide else 1024)
+    hidden_units = args.hidden_units or (100 if not wide else 4096)
+    hidden = [hidden_units] * (7 if wide else 1)
+    optimizer = args.optimizer or ("adam" if wide else "sgd")
+    lr = 0.01 if optimizer == "sgd" else 1e-3
+    train_rows = 55000 if not wide else max(8 * batch, 16384)
+    ds = mnist.synthetic_data_sets(train_size=train_rows, validation_size=100, test_size=100, seed=rank)
+    state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer=optimizer, lr=lr)
+    state.initialize(seed=1234)                      # same seed everywhere == chief init + broadcast
+    data = DeviceDataset(ds.train, device, shuffle_seed=1000 + rank)
+    fused = world == 1 and optimizer == "sgd"
+    prog = MLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, fused_update=fused,
+                      post_update_accuracy=not args.no_post_update_accuracy, gs_inc=1)
+    engine = SyncReplicasEngine(prog, state, collective=args.collective)
+    graph_steps = args.graph_steps or 64
+    _sync_all(device, world)
+    engine.run(args.warmup, graph_steps) if args.warmup > 0 else None
+    _sync_all(device, world)
+    t0 = time.perf_counter()
+    engine.run(args.steps, graph_steps)
+    _sync_all(device, world)
+    dt = time.perf_counter() - t0
+    dt = _max_over_ranks(dt, device, world)
+    gs = state.global_step()
+    assert gs == 1 + args.warmup + args.steps, (gs, args.warmup, args.steps)
+    last = prog.read_log(prog.steps_enqueued - 1, 1)[0]
+    value = batch * args.steps * world / dt
+    return {
+        "metric": METRIC, "value": value, "unit": "examples/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "fp32", "data": "synthetic MNIST-shape (resident in HBM), random-init weights",
+        "config": {"model": ("wide_mlp 784-7x4096-10" if wide else f"reference MLP 784-{hidden_units}-10"),
+                   "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
+                   "parallelism": f"dp{world} sync_replicas R={world}, ps state sharded over {world} GPU(s)",
+                   "optimizer": optimizer, "loss": "reference (softmax applied twice)", "mode": "sync",
+                   "collective": engine.collective if world > 1 else "none",
+                   "post_update_accuracy_pass": not args.no_post_update_accuracy,
+                   "hip_graph": bool(prog.use_graphs), "params": state.layout.used},
+        "final_loss": last.loss,
+    }
+
+
+def run_benchmark(args):
+    rank, world, device = _setup_distributed(args)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if args.config == "mlp_sync":
+        res = bench_mlp_sync(args, rank, world, device, wide=False)
+    elif args.config == "wide_mlp_sync":
+        res = bench_mlp_sync(args, rank, world, device, wide=True)
+    else:
+        raise SystemExit(f"config {args.config} is not wired into bench.py yet")
+    if world > 1:
+        comm.shutdown()
+    return res if rank == 0 else None

@@ -20,31 +20,65 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Out-of-range operand elements are read from this zero block instead of being guarded:
+// `ok ? *p : 0` is compiled into a branch around the load with its own s_waitcnt, which
+// serialises a batch of loads that must all be in flight together (these kernels are
+// latency bound).  Selecting the ADDRESS keeps every load unconditional.
+__device__ float4 dtf_zero16[2];
+__device__ __forceinline__ float ld_or_zero(const float* p, bool ok) {
+  return *(ok ? p : reinterpret_cast<const float*>(dtf_zero16));
+}
+__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
+  return *reinterpret_cast<const float4*>(ok ? p : reinterpret_cast<const float*>(dtf_zero16));
+}
+__device__ __forceinline__ int ldi_or_zero(const int* p, bool ok) {
+  return *(ok ? p : reinterpret_cast<const int*>(dtf_zero16));
+}
+
 // --------------------------------------------------------------------------------------
 // step tail
 // --------------------------------------------------------------------------------------
+// Runs in ONE workgroup of exactly 256 threads.
 __device__ __forceinline__ void dtf_tail_body(const DtfTailArgs& t, int tid, int nthreads, bool init_only) {
-  // Every thread reads the counters before anyone writes them.
+  __shared__ float s_loss[256];
+  __shared__ int s_cnt[256][2];
+  // Every thread reads the counters before thread 0 writes them (barriers below).
   const int gs = t.state[0];
   const int ls = t.state[1];
-  __syncthreads();
-  if (!init_only && tid == 0) {
+  if (!init_only) {
     float loss = 0.f;
     int correct = 0, post = 0;
-    for (int i = 0; i < t.nparts; ++i) {  // fixed order: the logged loss is bitwise reproducible
+    for (int i = tid; i < t.nparts; i += nthreads) {
       loss += t.loss_part[i];
       correct += t.correct_part[i];
       post += t.post_part[i];
     }
-    if (t.log) {
-      int* rec = t.log + 4 * (ls % t.log_cap);
-      rec[0] = __float_as_int(loss * t.inv_b);
-      rec[1] = correct;
-      rec[2] = post;
-      rec[3] = gs;  // value of global_step before this step's increment
+    s_loss[tid] = loss;
+    s_cnt[tid][0] = correct;
+    s_cnt[tid][1] = post;
+    __syncthreads();
+    // fixed-shape tree: the logged loss is bitwise reproducible
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        s_loss[tid] += s_loss[tid + s];
+        s_cnt[tid][0] += s_cnt[tid + s][0];
+        s_cnt[tid][1] += s_cnt[tid + s][1];
+      }
+      __syncthreads();
     }
-    t.state[0] = gs + t.gs_inc;
-    t.state[1] = ls + 1;
+    if (tid == 0) {
+      if (t.log) {
+        int* rec = t.log + 4 * (ls % t.log_cap);
+        rec[0] = __float_as_int(s_loss[0] * t.inv_b);
+        rec[1] = s_cnt[0][0];
+        rec[2] = s_cnt[0][1];
+        rec[3] = gs;  // value of global_step before this step's increment
+      }
+      t.state[0] = gs + t.gs_inc;
+      t.state[1] = ls + 1;
+    }
+  } else {
+    __syncthreads();
   }
   if (t.ridx_next) {
     const int next = init_only ? ls : ls + 1;
@@ -79,63 +113,91 @@ template <int NW, bool BT, bool VEC>
 __global__ __launch_bounds__(NW * 64) void small_gemm_kernel(DtfSmallGemmArgs p) {
   __shared__ float red[NW][4][64];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and provably so
   const int fr = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
 
   const int arow = m0 + fr;
   const bool arow_ok = arow < p.M;
-  const int asrc = arow_ok ? (p.a_rows ? p.a_rows[arow] : arow) : 0;
+  const int asrc = p.a_rows ? ldi_or_zero(p.a_rows + arow, arow_ok) : (arow_ok ? arow : 0);
   const float* __restrict__ aptr = p.A + (size_t)asrc * p.lda;
   const int bcol = n0 + fr;
   const bool bcol_ok = bcol < p.N;
   const float* __restrict__ bptr = BT ? p.B + (size_t)(bcol_ok ? bcol : 0) * p.ldb : p.B + (bcol_ok ? bcol : 0);
 
+  // Epilogue operands of the element this thread will finish (e = threadIdx.x, first 256 threads)
+  // are requested before the main loop so their latency is not paid after the reduction.
+  const int e_r = (threadIdx.x >> 6) & 3, e_ln = threadIdx.x & 63;
+  const int e_row = m0 + 4 * (e_ln >> 4) + e_r, e_col = n0 + (e_ln & 15);
+  const bool e_ok = threadIdx.x < 256 && e_row < p.M && e_col < p.N;
+  const float e_bias = p.bias ? ld_or_zero(p.bias + e_col, e_ok) : 0.f;
+  const float e_mask = p.mask ? ld_or_zero(p.mask + (size_t)e_row * p.ldmask + e_col, e_ok) : 1.f;
+
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const int nchunk = (p.K + 15) >> 4;
-#pragma unroll 4
-  for (int c = wave; c < nchunk; c += NW) {
-    const int k = (c << 4) + 4 * g;
-    float av[4], bv[4];
-    if (VEC) {
-      const float4 t = (arow_ok && k < p.K) ? *reinterpret_cast<const float4*>(aptr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
-    } else {
+  // The kernel is latency bound: issue the operand loads of CH k-chunks back to back (fully
+  // unrolled, guards are predicates not branches), then run their MFMAs.
+  constexpr int CH = 8;
+  for (int cb = wave; cb < nchunk; cb += NW * CH) {
+    float av[CH][4], bv[CH][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) av[j] = (arow_ok && k + j < p.K) ? aptr[k + j] : 0.f;
-    }
-    if (BT) {
+    for (int i = 0; i < CH; ++i) {
+      const int k = ((cb + i * NW) << 4) + 4 * g;
       if (VEC) {
-        const float4 t = (bcol_ok && k < p.K) ? *reinterpret_cast<const float4*>(bptr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+        const float4 t = ld4_or_zero(aptr + k, arow_ok && k < p.K);
+        av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = (bcol_ok && k + j < p.K) ? bptr[k + j] : 0.f;
+        for (int j = 0; j < 4; ++j) av[i][j] = ld_or_zero(aptr + k + j, arow_ok && k + j < p.K);
       }
-    } else {
+      if (BT) {
+        if (VEC) {
+          const float4 t = ld4_or_zero(bptr + k, bcol_ok && k < p.K);
+          bv[i][0] = t.x; bv[i][1] = t.y; bv[i][2] = t.z; bv[i][3] = t.w;
+        } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = (bcol_ok && k + j < p.K) ? bptr[(size_t)(k + j) * p.ldb] : 0.f;
+          for (int j = 0; j < 4; ++j) bv[i][j] = ld_or_zero(bptr + k + j, bcol_ok && k + j < p.K);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[i][j] = ld_or_zero(bptr + (size_t)(k + j) * p.ldb, bcol_ok && k + j < p.K);
+      }
     }
-    acc0 = MFMA16(av[0], bv[0], acc0);
-    acc1 = MFMA16(av[1], bv[1], acc1);
-    acc0 = MFMA16(av[2], bv[2], acc0);
-    acc1 = MFMA16(av[3], bv[3], acc1);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      acc0 = MFMA16(av[i][0], bv[i][0], acc0);
+      acc1 = MFMA16(av[i][1], bv[i][1], acc1);
+      acc0 = MFMA16(av[i][2], bv[i][2], acc0);
+      acc1 = MFMA16(av[i][3], bv[i][3], acc1);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
   __syncthreads();
-  for (int e = threadIdx.x; e < 256; e += NW * 64) {
-    const int r = e >> 6, ln = e & 63;
-    float s = 0.f;
+  if (NW >= 4) {
+    if (e_ok) {
+      float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) s += red[w][r][ln];
-    const int row = m0 + 4 * (ln >> 4) + r;
-    const int col = n0 + (ln & 15);
-    if (row < p.M && col < p.N) {
-      if (p.bias) s += p.bias[col];
+      for (int w = 0; w < NW; ++w) s += red[w][e_r][e_ln];
+      s += e_bias;
       if (p.relu) s = fmaxf(s, 0.f);
-      if (p.mask) s = p.mask[(size_t)row * p.ldmask + col] > 0.f ? s : 0.f;
-      p.C[(size_t)row * p.ldc + col] = s;
+      s = e_mask > 0.f ? s : 0.f;
+      p.C[(size_t)e_row * p.ldc + e_col] = s;
+    }
+  } else {
+    for (int e = threadIdx.x; e < 256; e += NW * 64) {
+      const int r = e >> 6, ln = e & 63;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[w][r][ln];
+      const int row = m0 + 4 * (ln >> 4) + r;
+      const int col = n0 + (ln & 15);
+      if (row < p.M && col < p.N) {
+        if (p.bias) s += p.bias[col];
+        if (p.relu) s = fmaxf(s, 0.f);
+        if (p.mask) s = p.mask[(size_t)row * p.ldmask + col] > 0.f ? s : 0.f;
+        p.C[(size_t)row * p.ldc + col] = s;
+      }
     }
   }
 }
@@ -179,7 +241,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, g = lane >> 4;
   const int tile = blockIdx.x * 4 + wave;
   if (tile >= p.total_tiles) return;
@@ -187,7 +249,8 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
 #pragma unroll
   for (int i = 1; i < DTF_MAX_WGRAD_PROBLEMS; ++i)
     if (i < p.nprob && tile >= p.prob[i].tile_start) pi = i;
-  const DtfWgradProblem& q = p.prob[pi];
+  // pi is wave-uniform: the problem descriptor comes out of the kernarg segment by scalar loads
+  const DtfWgradProblem q = p.prob[__builtin_amdgcn_readfirstlane(pi)];
   const int t = tile - q.tile_start;
   const int tn = t % q.tiles_n, tm = t / q.tiles_n;
   const int m0 = tm * 16, n0 = tn * 16;
@@ -197,25 +260,49 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
   const bool bn_ok = bn < q.N;
   const float* __restrict__ X = q.X;
   const float* __restrict__ dY = q.dY;
+  const int* __restrict__ xrows = q.x_rows;
 
+  // fused update: the old parameter values are requested up front, not after the MFMA chain
+  float wold[4] = {0.f, 0.f, 0.f, 0.f};
+  float bold = 0.f;
+  if (p.mode == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 4 * g + r;
+      wold[r] = ld_or_zero(q.W + (size_t)row * q.ldw + bn, row < q.Mo && bn_ok);
+    }
+    bold = ld_or_zero(q.b + bn, bn_ok);
+  }
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-#pragma unroll 2
-  for (int k0 = 0; k0 < q.Kb; k0 += 16) {
-    float av[4], bv[4];
+  constexpr int CH = 8;   // 128 batch rows per pass: row indices, then every operand load, then the MFMAs
+  for (int kb = 0; kb < q.Kb; kb += 16 * CH) {
+    int xr[CH][4];
+    float av[CH][4], bv[CH][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + 4 * j + g;
-      const bool kok = k < q.Kb;
-      const int xr = kok ? (q.x_rows ? q.x_rows[k] : k) : 0;
-      av[j] = (kok && am_ok) ? X[(size_t)xr * q.ldx + am] : 0.f;
-      bv[j] = (kok && bn_ok) ? dY[(size_t)k * q.ldy + bn] : 0.f;
-      bsum += bv[j];
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kb + 16 * i + 4 * j + g;
+        xr[i][j] = xrows ? ldi_or_zero(xrows + k, k < q.Kb) : k;
+      }
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kb + 16 * i + 4 * j + g;
+        const bool kok = k < q.Kb;
+        av[i][j] = ld_or_zero(X + (size_t)xr[i][j] * q.ldx + am, kok && am_ok);
+        bv[i][j] = ld_or_zero(dY + (size_t)k * q.ldy + bn, kok && bn_ok);
+      }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      bsum += (bv[i][0] + bv[i][1]) + (bv[i][2] + bv[i][3]);
+      acc0 = MFMA16(av[i][0], bv[i][0], acc0);
+      acc1 = MFMA16(av[i][1], bv[i][1], acc1);
+      acc0 = MFMA16(av[i][2], bv[i][2], acc0);
+      acc1 = MFMA16(av[i][3], bv[i][3], acc1);
     }
-    acc0 = MFMA16(av[0], bv[0], acc0);
-    acc1 = MFMA16(av[1], bv[1], acc1);
-    acc0 = MFMA16(av[2], bv[2], acc0);
-    acc1 = MFMA16(av[3], bv[3], acc1);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -223,7 +310,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
     if (row < q.Mo && bn_ok) {
       const float gval = acc0[r] + acc1[r];
       const size_t off = (size_t)row * q.ldw + bn;
-      if (p.mode == 1) q.W[off] -= p.lr * gval;
+      if (p.mode == 1) q.W[off] = wold[r] - p.lr * gval;
       else q.dW[off] = gval;
     }
   }
@@ -231,7 +318,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
     bsum += __shfl_xor(bsum, 16);
     bsum += __shfl_xor(bsum, 32);
     if (g == 0 && bn_ok) {
-      if (p.mode == 1) q.b[bn] -= p.lr * bsum;
+      if (p.mode == 1) q.b[bn] = bold - p.lr * bsum;
       else q.db[bn] = bsum;
     }
   }
@@ -288,58 +375,98 @@ __device__ __forceinline__ int group16_argmax(float v, int idx) {
   return idx;
 }
 
-__global__ __launch_bounds__(64) void head_kernel(DtfHeadArgs p) {
+// One workgroup = 4 waves = 16 rows.  The three dependent phases are each split over the
+// four waves so that the serial latency chain per wave stays short:
+//   A  z2 partial sums, k-chunks dealt round-robin to the waves (reduced through LDS)
+//   B  wave w does the softmax / loss / accuracy / dz2 math of rows 4g + w
+//   C  dz1 column chunks dealt round-robin to the waves
+__global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
+  __shared__ float red[4][4][64];
   __shared__ float dzs[16][17];
-  const int lane = threadIdx.x;
+  __shared__ float part_loss[4];
+  __shared__ int part_cnt[4][2];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, g = lane >> 4;
   const int r0 = blockIdx.x * 16;
   const int C = p.C, Hd = p.Hd;
   const float NEG_INF = -__builtin_huge_valf();
+  const bool cls_ok = fr < C;
+  const bool train_tile = r0 < p.M_train && p.dz1 != nullptr;   // workgroup-uniform
+  const int nchunk = (Hd + 15) >> 4;
+  constexpr int CH = 4;
 
-  // ---- z2 = Hact @ W2 (16 rows x 16 padded classes) ----
+  // ---- phase C operands of the first pass are requested first: they depend on nothing ----
+  float cw[CH][4], cact[CH][4];
+  auto load_c = [&](int cb) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int hcol = ((cb + 4 * i) << 4) + fr;
+      const bool h_ok = hcol < Hd;
+      const float* __restrict__ w2r = p.W2 + (size_t)hcol * C;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cw[i][j] = ld_or_zero(w2r + 4 * j + g, h_ok && 4 * j + g < C);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + 4 * g + r;
+        cact[i][r] = ld_or_zero(p.Hact + (size_t)row * p.ldh + hcol, h_ok && row < p.M_train);
+      }
+    }
+  };
+  if (train_tile) load_c(wave);
+
+  // ---- phase A: z2 = Hact @ W2 (16 rows x 16 padded classes), split-K over the waves ----
   const int arow = r0 + fr;
   const bool arow_ok = arow < p.M_total;
-  const float* __restrict__ hp = p.Hact + (size_t)(arow_ok ? arow : 0) * p.ldh;
-  const bool cls_ok = fr < C;
-  const float* __restrict__ wp = p.W2 + (cls_ok ? fr : 0);
+  const float* __restrict__ hp = p.Hact + (size_t)arow * p.ldh;
+  const float* __restrict__ wp = p.W2 + fr;
   const bool vec = ((p.ldh | Hd) & 3) == 0;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int k0 = 0; k0 < Hd; k0 += 16) {
-    const int k = k0 + 4 * g;
-    float av[4], bv[4];
-    if (vec) {
-      const float4 t = (arow_ok && k < Hd) ? *reinterpret_cast<const float4*>(hp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
-    } else {
+  for (int cb = wave; cb < nchunk; cb += 4 * CH) {
+    float av[CH][4], bv[CH][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) av[j] = (arow_ok && k + j < Hd) ? hp[k + j] : 0.f;
+    for (int i = 0; i < CH; ++i) {
+      const int k = ((cb + 4 * i) << 4) + 4 * g;
+      if (vec) {
+        const float4 t = ld4_or_zero(hp + k, arow_ok && k < Hd);
+        av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[i][j] = ld_or_zero(hp + k + j, arow_ok && k + j < Hd);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[i][j] = ld_or_zero(wp + (size_t)(k + j) * C, cls_ok && k + j < Hd);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bv[j] = (cls_ok && k + j < Hd) ? wp[(size_t)(k + j) * C] : 0.f;
-    acc0 = MFMA16(av[0], bv[0], acc0);
-    acc1 = MFMA16(av[1], bv[1], acc1);
-    acc0 = MFMA16(av[2], bv[2], acc0);
-    acc1 = MFMA16(av[3], bv[3], acc1);
+    for (int i = 0; i < CH; ++i) {
+      acc0 = MFMA16(av[i][0], bv[i][0], acc0);
+      acc1 = MFMA16(av[i][1], bv[i][1], acc1);
+      acc0 = MFMA16(av[i][2], bv[i][2], acc0);
+      acc1 = MFMA16(av[i][3], bv[i][3], acc1);
+    }
   }
-  const float bias = cls_ok ? p.b2[fr] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
+  // label / bias requests overlap the barrier
+  const int row = r0 + 4 * g + wave;            // the one row this lane group handles in phase B
+  const bool row_ok = row < p.M_total;
+  const bool train_row = row < p.M_train;
+  const int lrow = p.rows ? ldi_or_zero(p.rows + row, row_ok) : row;
+  const float lab = ld_or_zero(p.labels + (size_t)lrow * C + fr, row_ok && cls_ok);
+  const float bias = ld_or_zero(p.b2 + fr, cls_ok);
+  __syncthreads();
 
+  // ---- phase B ----
   float loss_acc = 0.f;
   int correct_acc = 0, post_acc = 0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = r0 + 4 * g + r;
-    const bool row_ok = row < p.M_total;
-    const bool train_row = row < p.M_train;
-    const float z = cls_ok ? acc0[r] + acc1[r] + bias : NEG_INF;
+  {
+    const float zsum = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
+    const float z = cls_ok ? zsum + bias : NEG_INF;
     const float zmax = group16_max(z);
     const float e1 = cls_ok ? expf(z - zmax) : 0.f;
     const float s1 = group16_sum(e1);
     const float y = e1 / s1;
-    const int lrow = row_ok ? (p.rows ? p.rows[row] : row) : 0;
-    const float lab = (row_ok && cls_ok) ? p.labels[(size_t)lrow * C + fr] : 0.f;
     if (p.probs && row_ok && cls_ok) p.probs[(size_t)row * C + fr] = y;
-
     float logp, dz;
     if (p.loss_mode == 0) {
       // softmax applied a second time on the probabilities (the reference feeds y as "logits")
@@ -360,14 +487,13 @@ __global__ __launch_bounds__(64) void head_kernel(DtfHeadArgs p) {
     const int am_l = group16_argmax(cls_ok ? lab : NEG_INF, fr);
     const int hit = (row_ok && am_y == am_l) ? 1 : 0;
     if (fr == 0) {
-      if (train_row) { loss_acc += lrow_loss; correct_acc += hit; }
-      else post_acc += hit;
+      if (train_row) { loss_acc = lrow_loss; correct_acc = hit; }
+      else post_acc = hit;
     }
     const float dzv = (train_row && cls_ok) ? dz : 0.f;
-    dzs[4 * g + r][fr] = dzv;
+    dzs[4 * g + wave][fr] = dzv;
     if (train_row && p.dz2) p.dz2[(size_t)row * 16 + fr] = dzv;
   }
-  // per-workgroup partials (lanes with fr == 0 hold them, one per 16-lane group)
   loss_acc += __shfl_xor(loss_acc, 16);
   loss_acc += __shfl_xor(loss_acc, 32);
   correct_acc += __shfl_xor(correct_acc, 16);
@@ -375,36 +501,38 @@ __global__ __launch_bounds__(64) void head_kernel(DtfHeadArgs p) {
   post_acc += __shfl_xor(post_acc, 16);
   post_acc += __shfl_xor(post_acc, 32);
   if (lane == 0) {
-    if (p.loss_part) p.loss_part[blockIdx.x] = loss_acc;
-    if (p.correct_part) p.correct_part[blockIdx.x] = correct_acc;
-    if (p.post_part) p.post_part[blockIdx.x] = post_acc;
+    part_loss[wave] = loss_acc;
+    part_cnt[wave][0] = correct_acc;
+    part_cnt[wave][1] = post_acc;
   }
-  if (r0 >= p.M_train || !p.dz1) return;  // wave-uniform: accuracy-only tile
   __syncthreads();
+  if (threadIdx.x == 0) {
+    // rows are summed in a fixed order: the logged loss is reproducible
+    if (p.loss_part) p.loss_part[blockIdx.x] = (part_loss[0] + part_loss[1]) + (part_loss[2] + part_loss[3]);
+    if (p.correct_part) p.correct_part[blockIdx.x] = part_cnt[0][0] + part_cnt[1][0] + part_cnt[2][0] + part_cnt[3][0];
+    if (p.post_part) p.post_part[blockIdx.x] = part_cnt[0][1] + part_cnt[1][1] + part_cnt[2][1] + part_cnt[3][1];
+  }
+  if (!train_tile) return;
 
-  // ---- dz1 = (dz2 @ W2^T) * (Hact > 0) ----
+  // ---- phase C: dz1 = (dz2 @ W2^T) * (Hact > 0), 16 columns per chunk ----
   float a4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) a4[j] = dzs[fr][4 * j + g];
-#pragma unroll 2
-  for (int h0 = 0; h0 < Hd; h0 += 16) {
-    const int hcol = h0 + fr;
-    const bool h_ok = hcol < Hd;
-    const float* __restrict__ w2r = p.W2 + (size_t)(h_ok ? hcol : 0) * C;
-    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-    float bv[4];
+  for (int cb = wave; cb < nchunk; cb += 4 * CH) {
+    if (cb != wave) load_c(cb);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bv[j] = (h_ok && 4 * j + g < C) ? w2r[4 * j + g] : 0.f;
-    d0 = MFMA16(a4[0], bv[0], d0);
-    d1 = MFMA16(a4[1], bv[1], d1);
-    d0 = MFMA16(a4[2], bv[2], d0);
-    d1 = MFMA16(a4[3], bv[3], d1);
+    for (int i = 0; i < CH; ++i) {
+      const int hcol = ((cb + 4 * i) << 4) + fr;
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+      d0 = MFMA16(a4[0], cw[i][0], d0);
+      d1 = MFMA16(a4[1], cw[i][1], d1);
+      d0 = MFMA16(a4[2], cw[i][2], d0);
+      d1 = MFMA16(a4[3], cw[i][3], d1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = r0 + 4 * g + r;
-      if (row < p.M_train && h_ok) {
-        const float act = p.Hact[(size_t)row * p.ldh + hcol];
-        p.dz1[(size_t)row * p.ld_dz1 + hcol] = act > 0.f ? d0[r] + d1[r] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const int orow = r0 + 4 * g + r;
+        if (orow < p.M_train && hcol < Hd)
+          p.dz1[(size_t)orow * p.ld_dz1 + hcol] = cact[i][r] > 0.f ? d0[r] + d1[r] : 0.f;
       }
     }
   }
@@ -416,6 +544,6 @@ DTF_EXPORT int dtf_head(const DtfHeadArgs* a, hipStream_t s) {
   if (a->C <= 0 || a->C > 16 || a->Hd <= 0 || a->ldh < a->Hd) return DTF_ERR_SHAPE;
   if (a->M_train > 0 && a->dz1 && a->ld_dz1 < a->Hd) return DTF_ERR_SHAPE;
   if (((a->ldh | a->Hd) & 3) == 0 && !dtf_aligned16(a->Hact)) return DTF_ERR_ALIGN;
-  hipLaunchKernelGGL(head_kernel, dim3(dtf_cdiv(a->M_total, 16)), dim3(64), 0, s, *a);
+  hipLaunchKernelGGL(head_kernel, dim3(dtf_cdiv(a->M_total, 16)), dim3(256), 0, s, *a);
   return dtf_check_launch();
 }

@@ -1,0 +1,275 @@
+"""The reference network as a device-side step program.
+
+Model: ``x[B,784] -> relu(x W1 + b1) -> softmax(h W2 + b2)`` with the loss and
+accuracy of /root/reference/distributed.py:78-87; any number of hidden layers
+is supported (the wide-MLP configuration), one is the reference.
+
+A *step program* owns every buffer of the training step and enqueues the whole
+step — forward, loss/accuracy, backward, weight gradients, optionally the SGD
+update, the counters and the selection of the next batch — on the current HIP
+stream without touching the host.  ``run(n)`` replays hipGraphs of such steps.
+
+Row layout of one step (``R = 2B`` rows when post-update accuracy is on):
+rows ``[0, B)`` are the training batch; rows ``[B, 2B)`` are the PREVIOUS
+batch, pushed through the forward pass again with the now-updated parameters
+only to count correct predictions.  That reproduces the reference's second
+``sess.run`` per iteration (train accuracy after the update, distributed.py:
+148-149) without a second set of launches.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .. import ops
+from ..data.device_dataset import DeviceDataset
+from ..parallel.sharded_state import ShardedState, mlp_variables
+
+
+@dataclass
+class StepRecord:
+    local_step: int          # 1-based, value of local_step after the increment (distributed.py:146)
+    global_step: int         # value fetched with the train op (before this step's own increment)
+    loss: float
+    train_correct: int       # correct predictions on the batch with the parameters it was trained from
+    post_correct: Optional[int] = None   # ... with the parameters after the update (None until known)
+    batch: int = 0
+
+    @property
+    def train_accuracy(self) -> float:
+        c = self.post_correct if self.post_correct is not None else self.train_correct
+        return c / float(self.batch)
+
+
+def hidden_names(n_hidden: int) -> List[str]:
+    return ["hid" if i == 0 else f"hid{i + 1}" for i in range(n_hidden)]
+
+
+class MLPProgram:
+    def __init__(self, state: ShardedState, dataset: DeviceDataset, batch: int, hidden: Sequence[int], classes: int = 10,
+                 loss_mode: int = ops.LOSS_REFERENCE, fused_update: bool = True, post_update_accuracy: bool = True,
+                 gs_inc: int = 1, log_capacity: int = 2048, use_graphs: Optional[bool] = None):
+        self.state, self.data = state, dataset
+        self.device = state.device
+        self.B, self.hidden, self.C = batch, list(hidden), classes
+        self.loss_mode = loss_mode
+        self.post = post_update_accuracy
+        self.fused = fused_update
+        if fused_update and (state.optimizer != "sgd" or state.world_size != 1):
+            raise ValueError("the update can only be fused into the weight-gradient epilogue for SGD on one rank")
+        self.gs_inc = gs_inc
+        self.R = 2 * batch if self.post else batch
+        self.is_cuda = self.device.type == "cuda"
+        self.use_graphs = self.is_cuda if use_graphs is None else (use_graphs and self.is_cuda)
+        dev, f32, i32 = self.device, torch.float32, torch.int32
+        self.names = hidden_names(len(self.hidden))
+        self.hact = [torch.zeros((self.R, h), dtype=f32, device=dev) for h in self.hidden]
+        self.dz = [torch.zeros((batch, h), dtype=f32, device=dev) for h in self.hidden]
+        self.dz2 = torch.zeros((batch, 16), dtype=f32, device=dev)
+        self.nblk = (self.R + 15) // 16
+        self.loss_part = torch.zeros(self.nblk, dtype=f32, device=dev)
+        self.correct_part = torch.zeros(self.nblk, dtype=i32, device=dev)
+        self.post_part = torch.zeros(self.nblk, dtype=i32, device=dev)
+        self.log_cap = log_capacity
+        self.log = torch.zeros((log_capacity, 4), dtype=i32, device=dev)
+        self.ridx = torch.zeros((2, 2 * batch), dtype=i32, device=dev)
+        self.steps_enqueued = 0           # host mirror of state[1] (counts enqueued, not necessarily finished, steps)
+        self._graphs: Dict = {}
+        self._eval_buf: Dict = {}
+        self._args = [self._build_args(0), self._build_args(1)] if self.is_cuda else None
+        self._started = False
+        # Called at the end of every step, inside the captured region: the engine's gradient
+        # aggregation + shard update + parameter redistribution when the update is not fused.
+        self.after_compute = None
+
+    # ------------------------------------------------------------------ argument packs (one per parity)
+    def _tail(self, q: int):
+        return ops.make_tail(self.state.state, self.log, self.loss_part, self.correct_part, self.post_part,
+                             ridx_cur=self.ridx[q], ridx_next=self.ridx[1 - q], perm=self.data.perm, batch=self.B,
+                             n_train=self.data.n, gs_inc=self.gs_inc)
+
+    def _wgrad_items(self, q: int):
+        st, items = self.state, []
+        for l, name in enumerate(self.names):
+            x = self.data.images if l == 0 else self.hact[l - 1]
+            rows = self.ridx[q] if l == 0 else None
+            items.append(ops.WgradItem(x, self.dz[l], self.B, rows=rows, dw=st.grad(f"{name}_w"), db=st.grad(f"{name}_b"),
+                                       w=st.var(f"{name}_w"), b=st.var(f"{name}_b")))
+        items.append(ops.WgradItem(self.hact[-1], self.dz2, self.B, n=self.C, dw=st.grad("sm_w"), db=st.grad("sm_b"),
+                                   w=st.var("sm_w"), b=st.var("sm_b")))
+        return items
+
+    def _build_args(self, q: int):
+        st = self.state
+        head = ops.build_head_args(self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B,
+                                   self.loss_mode, rows=self.ridx[q], dz2=self.dz2, dz1=self.dz[-1],
+                                   loss_part=self.loss_part, correct_part=self.correct_part, post_part=self.post_part)
+        items = self._wgrad_items(q)
+        wgrad = ops.build_wgrad_args(items, lr=st.lr if self.fused else None, tail=self._tail(q))
+        return {"head": head, "wgrad": wgrad, "items": items}
+
+    # ------------------------------------------------------------------ one step
+    def start(self) -> None:
+        """Select the rows of the first batch (runs once, before the first step)."""
+        self.steps_enqueued = self.state.local_step()
+        q = self.steps_enqueued & 1
+        self.data.prepare(self.steps_enqueued, 0, self.B)
+        if self.is_cuda:
+            t = ops.make_tail(self.state.state, ridx_cur=None, ridx_next=self.ridx[q], perm=self.data.perm, batch=self.B,
+                              n_train=self.data.n, gs_inc=0)
+            ops.step_tail(t, init_only=True)
+        else:
+            self._tail_cpu(q, init_only=True)
+        self._started = True
+
+    def enqueue_step(self) -> None:
+        """Enqueue one full training step on the current stream (no host synchronisation)."""
+        q = self.steps_enqueued & 1
+        st, rows = self.state, self.ridx[q]
+        x = self.data.images
+        for l, name in enumerate(self.names):
+            ops.linear_fwd(x, st.var(f"{name}_w"), st.var(f"{name}_b"), relu=True, rows=rows if l == 0 else None,
+                           out=self.hact[l], m=self.R)
+            x = self.hact[l]
+        if self.is_cuda:
+            ops.head(self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B,
+                     args=self._args[q]["head"])
+        else:
+            ops.head(self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B, self.loss_mode,
+                     rows=rows, dz2=self.dz2, dz1=self.dz[-1], loss_part=self.loss_part, correct_part=self.correct_part,
+                     post_part=self.post_part)
+        for l in range(len(self.names) - 1, 0, -1):
+            ops.linear_bwd_data(self.dz[l], st.var(f"{self.names[l]}_w"), act=self.hact[l - 1], out=self.dz[l - 1], m=self.B)
+        if self.is_cuda:
+            ops.wgrad_grouped(self._args[q]["items"], args=self._args[q]["wgrad"])
+        else:
+            ops.wgrad_grouped(self._wgrad_items(q), lr=st.lr if self.fused else None)
+            self._tail_cpu(q, init_only=False)
+        if self.after_compute is not None:
+            self.after_compute()
+        self.steps_enqueued += 1
+
+    def _tail_cpu(self, q: int, init_only: bool) -> None:
+        s = self.state.state
+        gs, ls = int(s[0]), int(s[1])
+        if not init_only:
+            rec = self.log[ls % self.log_cap]
+            loss = float(self.loss_part.sum()) * (1.0 / self.B)
+            rec[0] = struct.unpack("<i", struct.pack("<f", loss))[0]
+            rec[1] = int(self.correct_part.sum())
+            rec[2] = int(self.post_part.sum())
+            rec[3] = gs
+            s[0] = gs + self.gs_inc
+            s[1] = ls + 1
+        nxt = ls if init_only else ls + 1
+        pos = torch.arange(nxt * self.B, (nxt + 1) * self.B, dtype=torch.int64)
+        epoch, off = pos // self.data.n, pos % self.data.n
+        if self.data.perm is not None:
+            rows = self.data.perm[(epoch & 1), off].to(torch.int32)
+        else:
+            rows = off.to(torch.int32)
+        dst = self.ridx[q] if init_only else self.ridx[1 - q]
+        prev = rows if init_only else self.ridx[q][:self.B].clone()
+        dst[self.B:] = prev
+        dst[:self.B] = rows
+
+    # ------------------------------------------------------------------ multi-step execution
+    def _graph_for(self, n: int):
+        key = (n, self.steps_enqueued & 1)
+        g = self._graphs.get(key)
+        if g is None:
+            saved = self.steps_enqueued
+            # warm the kernels once outside capture is not needed: nothing here allocates or JIT-compiles
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(n):
+                    self.enqueue_step()
+            self.steps_enqueued = saved   # capture enqueues nothing
+            self._graphs[key] = g
+        return g
+
+    def run(self, n_steps: int, graph_steps: int = 64) -> None:
+        """Enqueue ``n_steps`` steps; returns without waiting for the device."""
+        if not self._started:
+            self.start()
+        limit = self.data.max_steps_per_launch(self.B)
+        graph_steps = max(2, min(graph_steps, limit) & ~1)
+        remaining = n_steps
+        while remaining > 0:
+            if self.use_graphs and remaining >= 2:
+                n = graph_steps if remaining >= graph_steps else 1 << (remaining.bit_length() - 1)
+                n = min(n, graph_steps)
+                self.data.prepare(self.steps_enqueued, n, self.B)
+                self._graph_for(n).replay()
+                self.steps_enqueued += n
+            else:
+                n = 1
+                self.data.prepare(self.steps_enqueued, 1, self.B)
+                self.enqueue_step()
+            remaining -= n
+
+    def read_log(self, first_local_step: int, count: int) -> List[StepRecord]:
+        """Records of local steps ``[first, first+count)`` (0-based).  Synchronises with the device."""
+        if count > self.log_cap:
+            raise ValueError("asked for more records than the log ring holds")
+        log = self.log.cpu()
+        out = []
+        for s in range(first_local_step, first_local_step + count):
+            rec = log[s % self.log_cap]
+            loss = struct.unpack("<f", struct.pack("<i", int(rec[0])))[0]
+            out.append(StepRecord(local_step=s + 1, global_step=int(rec[3]), loss=loss, train_correct=int(rec[1]),
+                                  batch=self.B))
+        if self.post:
+            # the post-update count of step s is produced by the accuracy-only rows of step s+1
+            for i, r in enumerate(out[:-1]):
+                nxt = log[(first_local_step + i + 1) % self.log_cap]
+                r.post_correct = int(nxt[2])
+        return out
+
+    def post_correct_of_last_step(self) -> int:
+        """Post-update accuracy count of the most recent step (needs one extra forward)."""
+        q = self.steps_enqueued & 1
+        rows = self.ridx[q][self.B:2 * self.B].contiguous()
+        return self._count_correct(self.data.images, self.data.labels, rows=rows, n=self.B)
+
+    # ------------------------------------------------------------------ evaluation
+    def _count_correct(self, images, labels, rows=None, n=None, chunk: int = 16384) -> int:
+        n = n if n is not None else images.shape[0]
+        st = self.state
+        total = 0
+        for lo in range(0, n, chunk):
+            m = min(chunk, n - lo)
+            key = m
+            buf = self._eval_buf.get(key)
+            if buf is None:
+                nb = (m + 15) // 16
+                buf = {"h": [torch.empty((m, h), dtype=torch.float32, device=self.device) for h in self.hidden],
+                       "lp": torch.zeros(nb, dtype=torch.float32, device=self.device),
+                       "cp": torch.zeros(nb, dtype=torch.int32, device=self.device),
+                       "pp": torch.zeros(nb, dtype=torch.int32, device=self.device)}
+                self._eval_buf = {key: buf}
+            if rows is not None:
+                r, xi, li = rows[lo:lo + m].contiguous(), images, labels
+            else:
+                r, xi, li = None, images[lo:lo + m], labels[lo:lo + m]
+            x = xi
+            for l, name in enumerate(self.names):
+                ops.linear_fwd(x, st.var(f"{name}_w"), st.var(f"{name}_b"), relu=True, rows=r if l == 0 else None,
+                               out=buf["h"][l], m=m)
+                x = buf["h"][l]
+            ops.head(x, st.var("sm_w"), st.var("sm_b"), li, m, 0, self.loss_mode, rows=r, loss_part=buf["lp"],
+                     correct_part=buf["cp"], post_part=buf["pp"])
+            total += int(buf["pp"].sum().item())
+        return total
+
+    def accuracy(self, images: torch.Tensor, labels: torch.Tensor) -> float:
+        """``accuracy.eval`` over a whole split in one go (distributed.py:141-142, :163-164)."""
+        return self._count_correct(images, labels) / float(images.shape[0])
+
+
+def build_mlp_state(input_dim: int, hidden: Sequence[int], classes: int, device, world_size=1, rank=0, optimizer="sgd",
+                    lr=0.01, **kw) -> ShardedState:
+    return ShardedState(mlp_variables(input_dim, hidden, classes), device, world_size, rank, optimizer, lr, **kw)

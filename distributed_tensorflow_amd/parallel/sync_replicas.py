@@ -1,0 +1,161 @@
+"""Synchronous aggregate-then-apply training (``tf.train.SyncReplicasOptimizer``
+as used at /root/reference/distributed.py:91-106, :128-131).
+
+Semantics kept from the reference:
+
+* an update applies the MEAN of ``replicas_to_aggregate`` (R) gradients, all
+  computed on the same parameter version;
+* ``global_step`` advances once per aggregated update;
+* R < num_workers: the slowest ``num_workers - R`` gradients of a step are
+  dropped (backup workers); R > num_workers: workers contribute more than once
+  per update;
+* workers leave a step together (the token queue is a barrier).
+
+What replaces the machinery: the per-variable ConditionalAccumulators on the
+ps and the chief's queue-runner thread become ONE reduce-scatter over the flat
+gradient buffer, the fused optimizer kernel on the slice this rank owns (scale
+1/R folded in), and ONE all-gather of the updated slices.  The token queue is
+the collective itself.  For R == num_workers the whole step — compute kernels,
+RCCL collectives, shard update — is captured in a hipGraph and the host is out
+of the loop.  For R != num_workers the set of contributors is decided per step
+from arrival times exchanged in a small all-gather, which needs the host.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from .comm import Collectives
+from .sharded_state import ShardedState
+
+# Below this many parameter bytes one all-reduce + replicated SGD beats reduce-scatter + all-gather
+# (two latency-bound collectives instead of one).  Only valid for stateless SGD.
+ALLREDUCE_BELOW_BYTES = 1 << 20
+
+
+class SyncReplicasEngine:
+    def __init__(self, program, state: ShardedState, group=None, replicas_to_aggregate: Optional[int] = None,
+                 total_num_replicas: Optional[int] = None, collective: str = "auto",
+                 arrival_delay: Optional[Callable[[int], float]] = None):
+        self.program, self.state = program, state
+        self.world = state.world_size
+        self.total = total_num_replicas if total_num_replicas is not None else self.world
+        if self.total != self.world:
+            raise ValueError("total_num_replicas must equal the number of worker ranks")
+        self.R = replicas_to_aggregate if replicas_to_aggregate is not None else self.world
+        if self.R <= 0:
+            raise ValueError("replicas_to_aggregate must be positive")
+        self.coll = Collectives(group) if self.world > 1 else None
+        if collective == "auto":
+            small = state.nbytes() < ALLREDUCE_BELOW_BYTES and state.optimizer == "sgd"
+            collective = "all_reduce" if small else "reduce_scatter"
+        if collective == "all_reduce" and state.optimizer != "sgd":
+            raise ValueError("the replicated all-reduce path is only defined for SGD")
+        self.collective = collective
+        self.fast = self.R == self.world
+        self.arrival_delay = arrival_delay      # test hook: artificial per-step compute delay of this rank
+        self._rs_out = torch.empty(state.layout.shard_size, dtype=torch.float32, device=state.device) \
+            if self.world > 1 else None
+        self._acc = None
+        self.updates_applied = 0
+        self.dropped = 0                        # gradients of THIS rank that were discarded as late
+        if self.world == 1:
+            # one rank: R gradients can only come from R successive batches on the same parameters
+            self.fast = self.R == 1
+        if program.gs_inc != (1 if self.fast else 0):
+            raise ValueError("program.gs_inc must be 1 on the fast path and 0 when the engine counts updates itself")
+        if program.fused and not (self.fast and self.world == 1):
+            raise ValueError("a program with the update fused into its epilogue only fits one rank with R == 1")
+        if self.fast and not program.fused:
+            program.after_compute = self._aggregate_and_apply if self.world > 1 else (lambda: state.apply_shard(None, 1.0))
+
+    # ------------------------------------------------------------------ fast path (R == num_workers)
+    def _aggregate_and_apply(self) -> None:
+        st = self.state
+        scale = 1.0 / self.R
+        if self.collective == "all_reduce":
+            self.coll.all_reduce_sum(st.grads)
+            st.apply_full(scale)
+        else:
+            self.coll.reduce_scatter_sum(self._rs_out, st.grads)
+            st.apply_shard(self._rs_out, scale)
+            self.coll.all_gather(st.params, st.param_shard)
+
+    def run(self, n_steps: int, graph_steps: int = 64) -> None:
+        """Run ``n_steps`` aggregated updates (each rank contributes as the R/num_workers ratio dictates)."""
+        if self.fast:
+            if self.world > 1 and self.program.use_graphs:
+                try:
+                    self.program.run(n_steps, graph_steps)
+                except RuntimeError:
+                    # collective capture not available in this build: same step, launched eagerly
+                    self.program.use_graphs = False
+                    self.program._graphs.clear()
+                    torch.cuda.synchronize()
+                    self.program.run(n_steps, graph_steps)
+            else:
+                self.program.run(n_steps, graph_steps)
+            self.updates_applied += n_steps
+            return
+        for _ in range(n_steps):
+            self._general_update()
+
+    # ------------------------------------------------------------------ general path (R != num_workers)
+    def _contribute(self):
+        """One gradient computation of this rank; returns its completion time."""
+        prog = self.program
+        saved, prog.use_graphs = prog.use_graphs, False
+        prog.run(1)
+        prog.use_graphs = saved
+        if self.state.device.type == "cuda":
+            torch.cuda.synchronize()
+        if self.arrival_delay is not None:
+            time.sleep(self.arrival_delay(self.updates_applied))
+        return time.time()
+
+    def _select_earliest(self, t_done: float, k: int) -> bool:
+        """True if this rank's gradient is among the k that arrived first (ties: lower rank)."""
+        if k >= self.world:
+            return True
+        mine = torch.tensor([t_done], dtype=torch.float64)
+        if self.coll.backend == "nccl":
+            mine = mine.to(self.state.device)
+        allt = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allt, mine, group=self.coll.group)
+        times = [float(t.item()) for t in allt]
+        order = sorted(range(self.world), key=lambda r: (times[r], r))
+        return self.coll.rank in order[:k]
+
+    def _general_update(self) -> None:
+        st, W, R = self.state, self.world, self.R
+        if self._acc is None:
+            self._acc = torch.zeros_like(st.grads)
+        rounds = (R + W - 1) // W
+        self._acc.zero_()
+        for rnd in range(rounds):
+            need = min(W, R - rnd * W)              # contributions taken in this round
+            t_done = self._contribute()
+            take = self._select_earliest(t_done, need) if W > 1 else True
+            if take:
+                ops.accumulate(self._acc, st.grads, 1.0, 1.0)
+            else:
+                self.dropped += 1
+        scale = 1.0 / R
+        if W == 1:
+            if st.optimizer == "sgd":
+                ops.sgd_apply(st.params, self._acc, st.lr, scale)
+            else:
+                st.apply_shard(self._acc[st.shard[0]:st.shard[1]], scale)
+        elif self.collective == "all_reduce":
+            self.coll.all_reduce_sum(self._acc)
+            ops.sgd_apply(st.params, self._acc, st.lr, scale)
+        else:
+            self.coll.reduce_scatter_sum(self._rs_out, self._acc)
+            st.apply_shard(self._rs_out, scale)
+            self.coll.all_gather(st.params, st.param_shard)
+        st.state[0:1].add_(1)                       # one global_step increment per aggregated update
+        self.updates_applied += 1

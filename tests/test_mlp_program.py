@@ -1,0 +1,114 @@
+"""Step program vs the NumPy oracle (CPU) and GPU vs CPU trajectories."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from distributed_tensorflow_amd import ops
+from distributed_tensorflow_amd.data import mnist
+from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+
+
+def _make(device, hidden=(100,), batch=100, lr=0.01, post=True, loss_mode=ops.LOSS_REFERENCE, n_train=1000, seed=5,
+          fused=True, use_graphs=None):
+    ds = mnist.synthetic_data_sets(train_size=n_train, validation_size=200, test_size=300, seed=seed)
+    st = build_mlp_state(784, list(hidden), 10, device, lr=lr)
+    init = oracle.init_params(hidden[0], seed=11) if len(hidden) == 1 else None
+    if init is not None:
+        st.load_values({k: torch.from_numpy(v).float() for k, v in init.items()})
+    else:
+        st.initialize(seed=11)
+    dd = DeviceDataset(ds.train, device, shuffle_seed=seed)
+    prog = MLPProgram(st, dd, batch, list(hidden), loss_mode=loss_mode, post_update_accuracy=post, fused_update=fused,
+                      use_graphs=use_graphs)
+    return ds, st, prog, init
+
+
+@pytest.mark.parametrize("loss", ["reference", "standard"])
+def test_cpu_program_matches_numpy_oracle(loss):
+    mode = ops.LOSS_REFERENCE if loss == "reference" else ops.LOSS_STANDARD
+    ds, st, prog, params = _make("cpu", lr=0.5, loss_mode=mode)
+    steps = 25
+    prog.run(steps)
+    recs = prog.read_log(0, steps)
+    for s in range(steps):
+        rows = ds.train.batch_rows(s * 100, 100)
+        x, y = ds.train.images[rows].astype(np.float64), ds.train.labels[rows].astype(np.float64)
+        l, acc, grads = oracle.loss_and_grads(params, x, y, loss)
+        params = oracle.sgd(params, grads, 0.5)
+        assert recs[s].global_step == s + 1          # global_step starts at 1 (distributed.py:65)
+        assert recs[s].local_step == s + 1
+        assert abs(recs[s].loss - l) < 2e-5, (s, recs[s].loss, l)
+        assert recs[s].train_correct == round(acc * 100)
+        if s < steps - 1:
+            assert recs[s].post_correct == round(oracle.accuracy(params, x, y) * 100)
+    for k, v in params.items():
+        np.testing.assert_allclose(st.var(k).numpy(), v, rtol=2e-4, atol=2e-6)
+    assert st.global_step() == steps + 1
+    assert prog.post_correct_of_last_step() == round(oracle.accuracy(params, x, y) * 100)
+
+
+def test_double_softmax_loss_is_bounded():
+    ds, st, prog, _ = _make("cpu", lr=2.0, n_train=500)
+    prog.run(60)
+    recs = prog.read_log(0, 60)
+    assert abs(recs[0].loss - np.log(10)) < 0.02
+    assert all(1.4611 <= r.loss <= 2.4612 for r in recs)    # -log(e/(e+9)) .. -log(1/(e+9))
+    assert recs[-1].loss < 1.6
+
+
+def test_epoch_rollover_batches_match_host_next_batch():
+    ds, st, prog, _ = _make("cpu", batch=64, n_train=200)    # 200 rows, batch 64: epochs end inside batches
+    prog.start()
+    for s in range(10):
+        want = ds.train.batch_rows(s * 64, 64)
+        got = prog.ridx[s & 1][:64].numpy()
+        np.testing.assert_array_equal(got, want)
+        x, _ = ds.train.next_batch(64)
+        np.testing.assert_array_equal(x, ds.train.images[want])
+        prog.run(1)
+
+
+def test_deep_mlp_cpu_matches_autograd():
+    ds, st, prog, _ = _make("cpu", hidden=(64, 48, 32), lr=0.1, loss_mode=ops.LOSS_STANDARD, fused=True)
+    w = {n: st.var(n).clone().requires_grad_(True) for n in st.names()}
+    rows = torch.from_numpy(ds.train.batch_rows(0, 100)).long()
+    x, y = torch.from_numpy(ds.train.images)[rows], torch.from_numpy(ds.train.labels)[rows]
+    h = x
+    for n in ("hid", "hid2", "hid3"):
+        h = torch.relu(h @ w[f"{n}_w"] + w[f"{n}_b"])
+    z = h @ w["sm_w"] + w["sm_b"]
+    loss = -(y * torch.log_softmax(z, 1)).sum(1).mean()
+    loss.backward()
+    prog.run(1)
+    rec = prog.read_log(0, 1)[0]
+    assert abs(rec.loss - loss.item()) < 1e-5
+    for n in st.names():
+        torch.testing.assert_close(st.var(n), (w[n] - 0.1 * w[n].grad).detach(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,post,graphs", [((100,), True, True), ((100,), False, False), ((64, 48), True, True)])
+def test_gpu_trajectory_matches_cpu(hidden, post, graphs):
+    steps = 37
+    _, st_c, prog_c, _ = _make("cpu", hidden=hidden, lr=0.3, post=post)
+    _, st_g, prog_g, _ = _make("cuda", hidden=hidden, lr=0.3, post=post, use_graphs=graphs)
+    if len(hidden) > 1:
+        st_g.load_values({n: st_c.var(n) for n in st_c.names()})
+    prog_c.run(steps)
+    prog_g.run(steps, graph_steps=8)
+    rc, rg = prog_c.read_log(0, steps), prog_g.read_log(0, steps)
+    for a, b in zip(rc, rg):
+        assert a.global_step == b.global_step and a.local_step == b.local_step
+        assert abs(a.loss - b.loss) < 1e-4
+        assert abs(a.train_correct - b.train_correct) <= 1
+        if post and a.post_correct is not None:
+            assert abs(a.post_correct - b.post_correct) <= 1
+    for n in st_c.names():
+        torch.testing.assert_close(st_g.var(n).cpu(), st_c.var(n), rtol=1e-3, atol=1e-5)
+    assert st_g.global_step() == steps + 1 and st_g.local_step() == steps
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=200, test_size=300, seed=5)
+    xt, yt = torch.from_numpy(ds.test.images), torch.from_numpy(ds.test.labels)
+    assert abs(prog_g.accuracy(xt.cuda(), yt.cuda()) - prog_c.accuracy(xt, yt)) < 0.01
+    assert prog_g.post_correct_of_last_step() == prog_c.post_correct_of_last_step()
