@@ -1,0 +1,250 @@
+"""Asynchronous (Hogwild-style) parameter-server training over point-to-point transfers.
+
+Reference behaviour (/root/reference/distributed.py:89, :102 with ``--sync_replicas``
+unset, the default): every worker applies its own gradient to the shared variables the
+moment it is computed — no aggregation, no barrier, no locking — and ``global_step``
+counts the updates of all workers together.
+
+Here the shared variables are ``num_shards`` contiguous slices of the flat parameter
+buffer, each resident in the HBM of its owner rank (ranks ``0 .. num_shards-1`` own one
+slice each and are workers as well).  A worker step is
+
+    compute gradients on the local replica
+    for every shard:   push = send(grad slice) to the owner        (side stream)
+                       pull = recv(updated slice) from the owner   (side stream)
+    continue with the next step; a pull may stay in flight for up to ``staleness`` steps
+
+and an owner runs a service thread that keeps one receive posted per remote worker on a
+dedicated two-rank communicator (so arrivals complete in any order), applies each arriving
+gradient to its slice with the fused SGD kernel, bumps ``global_step`` (owner of shard 0)
+and sends the fresh slice back.  ``backend='nccl'`` is RCCL over xGMI; ``gloo`` runs the
+same code on CPU.  Races between an owner's compute reading its slice and the service
+thread updating it are intended (lock-free updates, as the reference's use_locking=False).
+
+Wire format of one message (float32 buffer of ``shard_size + 2`` elements; the two extra
+slots carry int32 bit patterns): push = [grad..., kind, worker_local_step] with kind
+0 = gradient, 1 = worker finished, 2 = pull only; reply = [params..., global_step, 0].
+"""
+from __future__ import annotations
+
+import threading
+import time
+from collections import deque
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from .sharded_state import ShardedState
+
+KIND_GRAD, KIND_DONE, KIND_PULL = 0, 1, 2
+
+
+def build_pair_groups(world: int, num_shards: int) -> Dict[Tuple[int, int], object]:
+    """One two-rank group per (owner, worker) pair.  Collective: every rank must call this
+    with the same arguments, in the same order."""
+    groups = {}
+    for o in range(num_shards):
+        for w in range(world):
+            if w != o:
+                groups[(o, w)] = dist.new_group([o, w])
+    return groups
+
+
+class AsyncParameterServerEngine:
+    def __init__(self, program, state: ShardedState, num_shards: int = 1, staleness: int = 4,
+                 pair_groups: Optional[Dict] = None):
+        self.program, self.state = program, state
+        self.world, self.rank = state.world_size, state.rank
+        if program.fused or program.gs_inc != 0:
+            raise ValueError("async mode needs a program that stores gradients and leaves global_step to the owner")
+        self.S = max(1, min(num_shards, self.world))
+        self.staleness = max(0, staleness)
+        self.device = state.device
+        n = state.layout.total
+        if n % self.S:
+            # the flat buffer is padded to world*ALIGN, so any S that divides world divides it
+            raise ValueError(f"{self.S} shards do not divide the flat buffer of {n} elements")
+        self.slice = n // self.S
+        self.groups = pair_groups if pair_groups is not None else (
+            build_pair_groups(self.world, self.S) if self.world > 1 else {})
+        f32 = torch.float32
+        self.is_owner = self.rank < self.S
+        # worker side: per remote shard a ring of staleness+1 push/pull staging buffers — at most
+        # `staleness` exchanges are still in flight when a new one starts, so a free slot always exists
+        self._ring = self.staleness + 1
+        remote = [s for s in range(self.S) if s != self.rank]
+        self._push_buf = {s: torch.zeros((self._ring, self.slice + 2), dtype=f32, device=self.device) for s in remote}
+        self._pull_buf = {s: torch.zeros((self._ring, self.slice + 2), dtype=f32, device=self.device) for s in remote}
+        self._exchanges = 0
+        self._pending = deque()          # (slot, [(shard, send_work, recv_work)])
+        self.updates_pushed = 0
+        self.last_global_step = 1
+        # owner side: one service thread per remote worker, each blocking on its own two-rank group
+        # (and, on GPU, issuing on its own stream), so arrivals are served in any order
+        self._threads: List[threading.Thread] = []
+        self._service_error: Optional[BaseException] = None
+        self._applied = 0
+        # global_step lives with the owner of shard 0; host-side under a lock so that concurrent
+        # service threads and the owner's own pushes never lose an increment
+        self._gs_lock = threading.Lock()
+        self._gs = 1
+        if self.is_owner and self.world > 1:
+            self._in = {w: torch.zeros(self.slice + 2, dtype=f32, device=self.device) for w in range(self.world) if w != self.rank}
+            self._out = {w: torch.zeros(self.slice + 2, dtype=f32, device=self.device) for w in range(self.world) if w != self.rank}
+            for w in self._in:
+                t = threading.Thread(target=self._serve, args=(w,), name=f"dtf-ps-service-{w}", daemon=True)
+                t.start()
+                self._threads.append(t)
+
+    # ------------------------------------------------------------------ helpers
+    def _shard_range(self, s: int) -> Tuple[int, int]:
+        return s * self.slice, (s + 1) * self.slice
+
+    @staticmethod
+    def _ints(buf: torch.Tensor) -> torch.Tensor:
+        return buf[-2:].view(torch.int32)
+
+    # ------------------------------------------------------------------ owner service threads
+    def _bump_global_step(self) -> int:
+        with self._gs_lock:
+            self._gs += 1
+            self._applied += 1
+            return self._gs
+
+    def _serve(self, w: int) -> None:
+        try:
+            if self.device.type == "cuda":
+                with torch.cuda.stream(torch.cuda.Stream(self.device)):
+                    self._serve_loop(w)
+            else:
+                self._serve_loop(w)
+        except BaseException as e:  # surfaced by the training thread
+            self._service_error = e
+
+    def _serve_loop(self, w: int) -> None:
+        st = self.state
+        lo, hi = self._shard_range(self.rank)
+        master = st.params[lo:hi]
+        group = self.groups[(self.rank, w)]
+        msg, out = self._in[w], self._out[w]
+        while True:
+            dist.recv(msg, src=w, group=group)
+            kind = int(self._ints(msg)[0].item())
+            if kind == KIND_DONE:
+                return
+            gs = None
+            if kind == KIND_GRAD:
+                # lock-free apply on the owned slice (ApplyGradientDescent on the ps, use_locking=False)
+                ops.sgd_apply(master, msg[:self.slice], st.lr, 1.0)
+                if self.rank == 0:
+                    gs = self._bump_global_step()   # global_step counts every worker's update
+                else:
+                    with self._gs_lock:
+                        self._applied += 1
+            if gs is None:
+                with self._gs_lock:
+                    gs = self._gs
+            out[:self.slice].copy_(master)
+            self._ints(out)[0] = gs
+            dist.send(out, dst=w, group=group)
+
+    # ------------------------------------------------------------------ worker side
+    def _complete_oldest(self) -> None:
+        slot, works = self._pending.popleft()
+        st = self.state
+        for s, send_w, recv_w in works:
+            send_w.wait()
+            recv_w.wait()
+            lo, hi = self._shard_range(s)
+            buf = self._pull_buf[s][slot]
+            st.params[lo:hi].copy_(buf[:self.slice])
+            if s == 0:
+                st.state[0:1].copy_(self._ints(buf)[0:1])
+
+    def _exchange(self, kind: int) -> None:
+        """Push (gradient / control) to every remote owner and post the matching pulls."""
+        st = self.state
+        works = []
+        while len(self._pending) >= self._ring:
+            self._complete_oldest()
+        slot = self._exchanges % self._ring
+        self._exchanges += 1
+        for s in range(self.S):
+            lo, hi = self._shard_range(s)
+            if s == self.rank:
+                if kind == KIND_GRAD:
+                    ops.sgd_apply(st.params[lo:hi], st.grads[lo:hi], st.lr, 1.0)
+                    if s == 0:
+                        st.state[0] = self._bump_global_step()
+                    else:
+                        with self._gs_lock:
+                            self._applied += 1
+                continue
+            buf = self._push_buf[s][slot]
+            if kind == KIND_GRAD:
+                buf[:self.slice].copy_(st.grads[lo:hi])
+            ints = self._ints(buf)
+            ints[0] = kind
+            ints[1] = self.updates_pushed
+            g = self.groups[(s, self.rank)]
+            send_w = dist.isend(buf, dst=s, group=g)
+            if kind == KIND_DONE:
+                send_w.wait()
+                continue
+            recv_w = dist.irecv(self._pull_buf[s][slot], src=s, group=g)
+            works.append((s, send_w, recv_w))
+        if works:
+            self._pending.append((slot, works))
+
+    def _check_service(self) -> None:
+        if self._service_error is not None:
+            raise RuntimeError("parameter-service thread failed") from self._service_error
+
+    def step(self) -> None:
+        """One asynchronous worker step."""
+        self._check_service()
+        # staleness bound: at most `staleness` of my own pushes may be missing from the replica I compute on
+        while len(self._pending) > self.staleness:
+            self._complete_oldest()
+        prog = self.program
+        saved, prog.use_graphs = prog.use_graphs, False
+        prog.run(1)
+        prog.use_graphs = saved
+        self._exchange(KIND_GRAD)
+        self.updates_pushed += 1
+
+    def run(self, n_steps: int, graph_steps: int = 0) -> None:
+        for _ in range(n_steps):
+            self.step()
+
+    def sync_params(self) -> int:
+        """Drain outstanding pulls and fetch the owners' current values (used before evaluation).
+        Returns the freshest global_step this worker knows."""
+        while self._pending:
+            self._complete_oldest()
+        if self._pull_buf:
+            self._exchange(KIND_PULL)
+            while self._pending:
+                self._complete_oldest()
+        self.last_global_step = self.state.global_step()
+        return self.last_global_step
+
+    def finish(self) -> None:
+        """This worker is done: tell the owners, then (owners) keep serving until everyone is done."""
+        while self._pending:
+            self._complete_oldest()
+        if self.world > 1:
+            self._exchange(KIND_DONE)
+        for t in self._threads:
+            t.join()
+        self._check_service()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        if self.rank == 0:
+            self.state.state[0] = self._gs
+
+    @property
+    def updates_applied_here(self) -> int:
+        return self._applied

@@ -1,0 +1,121 @@
+"""Session lifecycle: chief init-or-restore, wait-for-ready, periodic checkpoints, step rate
+(``tf.train.Supervisor`` as used at /root/reference/distributed.py:108-111, :121-126).
+
+* The chief restores the newest checkpoint of ``logdir`` if there is one, otherwise runs the
+  init function (``global_variables_initializer``), then publishes readiness.
+* Every other worker polls for readiness once per ``recovery_wait_secs`` (1 s in the reference)
+  and then receives the chief's values.
+* The chief saves ``model.ckpt-<global_step>`` every ``save_model_secs`` (600 s, the Supervisor
+  default) and once more at ``stop()``; it also reports ``global_step/sec`` every 120 s.
+
+Checkpoints are taken by the training loop between hipGraph launches (``maybe_checkpoint``),
+not by a timer thread racing the update kernels: the snapshot is always a consistent parameter
+version.
+"""
+from __future__ import annotations
+
+import json
+import os
+import tempfile
+import time
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from ..checkpoint.saver import Saver, latest_checkpoint
+
+
+class Supervisor:
+    def __init__(self, is_chief: bool, logdir: Optional[str], init_fn: Callable[[], None], state,
+                 recovery_wait_secs: float = 1.0, save_model_secs: float = 600.0, save_summaries_secs: float = 120.0,
+                 store=None, group_size: int = 1, saver: Optional[Saver] = None, log: Callable[[str], None] = print):
+        self.is_chief = is_chief
+        self.logdir = logdir if logdir is not None else tempfile.mkdtemp()   # distributed.py:109
+        self.init_fn = init_fn
+        self.state = state
+        self.recovery_wait_secs = recovery_wait_secs
+        self.save_model_secs = save_model_secs
+        self.save_summaries_secs = save_summaries_secs
+        self.store = store
+        self.group_size = group_size
+        self.saver = saver or Saver()
+        self.log = log
+        self.restored_from: Optional[str] = None
+        self._last_save = time.time()
+        self._last_rate_time = time.time()
+        self._last_rate_step: Optional[int] = None
+        self.waited_polls = 0
+        self._events = None
+
+    # ------------------------------------------------------------------ session bring-up
+    def prepare_or_wait_for_session(self) -> None:
+        st = self.state
+        if self.is_chief:
+            ckpt = latest_checkpoint(self.logdir)
+            if ckpt is not None:
+                values = Saver.restore(ckpt)
+                st.load_values({k: torch.from_numpy(v) for k, v in values.items() if k != "global_step"},
+                               global_step=int(values["global_step"]))
+                self.restored_from = ckpt
+            else:
+                self.init_fn()
+            if self.store is not None:
+                self.store.set("dtf/ready", "1")
+        else:
+            if self.store is None:
+                raise RuntimeError("a non-chief worker needs a rendezvous store to wait for the chief")
+            while not self.store.check(["dtf/ready"]):
+                self.waited_polls += 1
+                time.sleep(self.recovery_wait_secs)
+        if self.group_size > 1 and dist.is_initialized():
+            # every worker receives the chief's variables (the reference's workers read them from the ps)
+            dist.broadcast(st.params, src=0)
+            dist.broadcast(st.state, src=0)
+            st.initialized = True
+        self._last_save = time.time()
+        self._last_rate_time = time.time()
+        self._last_rate_step = None
+
+    # ------------------------------------------------------------------ services driven by the training loop
+    def save(self, global_step: Optional[int] = None) -> Optional[str]:
+        if not self.is_chief:
+            return None
+        tensors = self.state.named_tensors()
+        gs = int(tensors["global_step"]) if global_step is None else global_step
+        path = self.saver.save(tensors, self.logdir, gs)
+        self._last_save = time.time()
+        return path
+
+    def maybe_checkpoint(self) -> Optional[str]:
+        if not self.is_chief or not self.save_model_secs:
+            return None
+        if time.time() - self._last_save >= self.save_model_secs:
+            return self.save()
+        return None
+
+    def report_step_rate(self, global_step: int, force: bool = False) -> Optional[float]:
+        """``global_step/sec`` summary (Supervisor writes it because ``global_step=`` was passed, :111)."""
+        now = time.time()
+        if self._last_rate_step is None:
+            self._last_rate_step, self._last_rate_time = global_step, now
+            return None
+        if not force and now - self._last_rate_time < self.save_summaries_secs:
+            return None
+        dt = max(now - self._last_rate_time, 1e-9)
+        rate = (global_step - self._last_rate_step) / dt
+        self._last_rate_step, self._last_rate_time = global_step, now
+        if self.is_chief:
+            if self._events is None:
+                os.makedirs(self.logdir, exist_ok=True)
+                self._events = open(os.path.join(self.logdir, "events.jsonl"), "a")
+            self._events.write(json.dumps({"wall_time": now, "step": global_step, "global_step/sec": rate}) + "\n")
+            self._events.flush()
+        return rate
+
+    def stop(self, save: bool = True) -> None:
+        if save and self.is_chief and self.save_model_secs:
+            self.save()
+        if self._events is not None:
+            self._events.close()
+            self._events = None

@@ -1,0 +1,52 @@
+"""Spawn helpers for multi-process CPU (gloo) tests."""
+import os
+import socket
+import sys
+import traceback
+
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _entry(rank, world, port, fn, args, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      OMP_NUM_THREADS="1")
+    import torch
+    torch.set_num_threads(1)
+    try:
+        q.put((rank, "ok", fn(rank, world, port, *args)))
+    except BaseException:  # noqa
+        q.put((rank, "err", traceback.format_exc()))
+
+
+def run_ranks(fn, world, *args, timeout=240):
+    """Run ``fn(rank, world, port, *args)`` in ``world`` processes; returns results by rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_entry, args=(r, world, port, fn, args, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(world):
+            rank, status, payload = q.get(timeout=timeout)
+            if status != "ok":
+                raise AssertionError(f"rank {rank} failed:\n{payload}")
+            results[rank] = payload
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    return [results[r] for r in range(world)]

@@ -1,0 +1,53 @@
+"""Asynchronous push/pull engine on gloo (CPU, 3-4 ranks)."""
+import pytest
+import torch
+import torch.distributed as dist
+
+from dist_utils import run_ranks
+
+
+def _async_worker(rank, world, port, num_shards, staleness, steps):
+    from distributed_tensorflow_amd import ops
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterServerEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=100, test_size=300, seed=rank)
+    st = build_mlp_state(784, [32], 10, "cpu", world_size=world, rank=rank, lr=0.5)
+    st.initialize(seed=3)
+    prog = MLPProgram(st, DeviceDataset(ds.train, "cpu", shuffle_seed=rank), 50, [32], fused_update=False, gs_inc=0,
+                      post_update_accuracy=False)
+    eng = AsyncParameterServerEngine(prog, st, num_shards=num_shards, staleness=staleness)
+    first = None
+    for i in range(steps):
+        eng.step()
+        if i == 0:
+            first = prog.read_log(0, 1)[0].loss
+    gs_seen = eng.sync_params()
+    last = prog.read_log(steps - 1, 1)[0].loss
+    xt, yt = torch.from_numpy(ds.test.images), torch.from_numpy(ds.test.labels)
+    acc = prog.accuracy(xt, yt)
+    eng.finish()
+    dist.barrier()
+    final_gs = st.global_step()
+    params = st.params.clone()
+    dist.destroy_process_group()
+    return {"first": first, "last": last, "acc": acc, "gs_seen": gs_seen, "final_gs": final_gs,
+            "applied": eng.updates_applied_here, "checksum": float(params.double().sum())}
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("world,num_shards,staleness", [(3, 1, 0), (3, 1, 4), (4, 2, 2)])
+def test_async_counts_every_update_and_converges(world, num_shards, staleness):
+    steps = 40
+    res = run_ranks(_async_worker, world, num_shards, staleness, steps)
+    # global_step starts at 1 and counts the updates of ALL workers (distributed.py:65, :102)
+    assert res[0]["final_gs"] == 1 + world * steps
+    # every owner applied one gradient slice per worker step
+    for r in range(num_shards):
+        assert res[r]["applied"] == world * steps
+    for r in res:
+        assert r["last"] < r["first"] - 0.3           # loss fell (reference loss is bounded in [1.46, 2.46])
+        assert r["acc"] > 0.5
+        assert 1 + steps <= r["gs_seen"] <= 1 + world * steps
