@@ -1,0 +1,265 @@
+"""Training driver with the behaviour of /root/reference/distributed.py:37-165.
+
+Same flags, same role handling, same log lines (typos included), same loop
+rules: validation accuracy every 10000 local steps including step 0 (:140-143),
+per-step line with loss and training accuracy (:152-153), stop once the
+``global_step`` fetched with the train op reaches ``--train_steps`` (:155-156),
+then elapsed time and test accuracy (:158-165).
+
+What differs is where the work happens: steps are replayed in hipGraph
+launches of many steps each, logs come back in batches from a device-side
+ring, and the per-step host round trips of the reference (two session runs, two
+feeds, one global_step fetch) do not exist.
+"""
+from __future__ import annotations
+
+import sys
+import time
+from typing import List, Optional
+
+import torch
+
+from . import flags as flags_lib
+from . import ops
+from .cluster.server import Server
+from .cluster.spec import ClusterSpec, Role, split_hosts, validate_role
+from .data import mnist
+from .data.device_dataset import DeviceDataset
+from .models.mlp import MLPProgram, StepRecord, build_mlp_state
+from .parallel.async_ps import AsyncParameterServerEngine
+from .parallel.sync_replicas import SyncReplicasEngine
+from .supervisor.supervisor import Supervisor
+
+FLAGS = flags_lib.FLAGS
+IMAGE_PIXELS = 28   # distributed.py:35
+
+_defined = False
+
+
+def define_flags() -> None:
+    global _defined
+    if not _defined:
+        flags_lib.define_reference_flags()
+        flags_lib.define_framework_flags()
+        _defined = True
+
+
+def resolve_device(role: Optional[Role], requested: str) -> torch.device:
+    """``allow_soft_placement=True`` (distributed.py:114): use the GPU when there is one, else the CPU."""
+    if requested == "cpu":
+        return torch.device("cpu")
+    if torch.cuda.is_available():
+        n = torch.cuda.device_count()
+        idx = role.local_rank() % n if role is not None and role.is_worker else 0
+        return torch.device("cuda", idx)
+    if requested == "gpu":
+        raise RuntimeError("--device=gpu but no GPU is visible")
+    return torch.device("cpu")
+
+
+def _emit(line: str) -> None:
+    sys.stdout.write(line + "\n")
+
+
+class TrainingLoop:
+    """The ``while True`` loop of distributed.py:135-156 in launches of many steps."""
+
+    def __init__(self, task_index: int, program: MLPProgram, engine, train_steps: int, validation_every: int,
+                 log_every: int, steps_per_launch: int, validation, test, supervisor: Optional[Supervisor],
+                 is_async: bool, world: int, emit=_emit):
+        self.task, self.prog, self.engine = task_index, program, engine
+        self.train_steps, self.validation_every = train_steps, max(1, validation_every)
+        self.log_every = max(1, log_every)
+        self.steps_per_launch = steps_per_launch
+        self.validation, self.test = validation, test
+        self.sv = supervisor
+        self.is_async, self.world = is_async, world
+        self.emit = emit
+        self.local_step = 0
+        self.records: List[StepRecord] = []      # everything printed, for callers that want the trajectory
+        self.keep_records = False
+        self.validation_accuracies: List[float] = []
+
+    def _print_record(self, r: StepRecord) -> None:
+        if self.keep_records:
+            self.records.append(r)
+        if r.local_step % self.log_every == 0:
+            self.emit('Worker %d: traing step %d (global step:%d) loss %f training accuracy %g'
+                      % (self.task, r.local_step, r.global_step, r.loss, r.train_accuracy))
+
+    def _validate(self) -> None:
+        if self.is_async:
+            self.engine.sync_params()
+        acc = self.prog.accuracy(*self.validation)
+        self.validation_accuracies.append(acc)
+        self.emit('Worker %d: validation accuracy %g' % (self.task, acc))
+
+    def _plan(self, last_seen_gs: int) -> int:
+        to_validation = self.validation_every - (self.local_step % self.validation_every)
+        if self.is_async:
+            # other workers advance global_step too: approach the limit in shrinking launches
+            remaining = max(1, (self.train_steps - last_seen_gs + 1) // max(1, self.world))
+        else:
+            # the fetched value is global_step before the step's own increment
+            remaining = max(1, self.train_steps - last_seen_gs + 1)
+        cap = self.steps_per_launch if self.steps_per_launch > 0 else 256
+        cap = min(cap, self.prog.log_cap - 1, self.prog.data.max_steps_per_launch(self.prog.B))
+        return max(1, min(cap, remaining, to_validation))
+
+    def run(self) -> float:
+        prog = self.prog
+        time_begin = time.time()
+        held: Optional[StepRecord] = None        # last record of the previous launch, waiting for its post-update accuracy
+        done = False
+        gs_seen = prog.state.global_step()
+        while not done:
+            if self.local_step % self.validation_every == 0:
+                if held is not None:             # keep the reference's line order: step line, then validation
+                    held.post_correct = prog.post_correct_of_last_step()
+                    self._print_record(held)
+                    held = None
+                self._validate()
+            n = self._plan(gs_seen)
+            first = self.local_step
+            self.engine.run(n, min(n, 64) if n >= 2 else 1)
+            self.local_step += n
+            recs = prog.read_log(first, n)       # synchronises with the device
+            if held is not None:
+                # the accuracy-only rows of this launch's first step re-scored the held step's batch
+                held.post_correct = self._post_of_previous(first)
+                self._print_record(held)
+                held = None
+            for i, r in enumerate(recs):
+                stop_here = r.global_step >= self.train_steps
+                if prog.post and r.post_correct is None:          # only the last record of a launch
+                    if not stop_here:
+                        held = r
+                        break
+                    r.post_correct = prog.post_correct_of_last_step()
+                self._print_record(r)
+                if stop_here:
+                    done = True
+                    break
+            gs_seen = recs[-1].global_step + 1
+            if self.sv is not None:
+                self.sv.maybe_checkpoint()
+                self.sv.report_step_rate(gs_seen)
+        time_end = time.time()
+        return time_end - time_begin
+
+    def _post_of_previous(self, first_local_step: int) -> int:
+        log = self.prog.log[first_local_step % self.prog.log_cap].cpu()
+        return int(log[2])
+
+
+def build_worker(role: Optional[Role], device: torch.device, datasets, hidden_units: int, batch_size: int,
+                 learning_rate: float, sync_replicas: bool, replicas_to_aggregate: Optional[int], world: int, rank: int,
+                 optimizer: str = "sgd", loss: str = "reference", post_update_accuracy: bool = True, hidden_layers: int = 1,
+                 staleness: int = 4, num_ps: int = 1, seed: int = 0, collective: str = "auto"):
+    """Graph construction of distributed.py:60-102, as device-side state + step program + engine."""
+    hidden = [hidden_units] * max(1, hidden_layers)
+    state = build_mlp_state(IMAGE_PIXELS * IMAGE_PIXELS, hidden, 10, device, world_size=world, rank=rank,
+                            optimizer=optimizer, lr=learning_rate)
+    data = DeviceDataset(datasets.train, device, shuffle_seed=(seed * 7919 + rank))
+    loss_mode = ops.LOSS_REFERENCE if loss == "reference" else ops.LOSS_STANDARD
+    if sync_replicas or world == 1:
+        R = replicas_to_aggregate if (sync_replicas and replicas_to_aggregate is not None) else world
+        if not sync_replicas:
+            R = 1
+        fast = (R == world)
+        fused = fast and world == 1 and optimizer == "sgd"
+        prog = MLPProgram(state, data, batch_size, hidden, loss_mode=loss_mode, fused_update=fused,
+                          post_update_accuracy=post_update_accuracy, gs_inc=1 if fast else 0)
+        engine = SyncReplicasEngine(prog, state, replicas_to_aggregate=R, collective=collective)
+        is_async = False
+    else:
+        if optimizer != "sgd":
+            raise ValueError("async mode implements the reference's plain SGD")
+        prog = MLPProgram(state, data, batch_size, hidden, loss_mode=loss_mode, fused_update=False,
+                          post_update_accuracy=post_update_accuracy, gs_inc=0)
+        engine = AsyncParameterServerEngine(prog, state, num_shards=num_ps, staleness=staleness)
+        is_async = True
+    return state, prog, engine, is_async
+
+
+def main(unused_argv=None) -> int:
+    define_flags()
+    datasets = mnist.load(FLAGS.data_dir, FLAGS.synthetic_data, seed=FLAGS.seed,
+                          synthetic_train_size=FLAGS.synthetic_train_size)                 # distributed.py:38
+
+    if FLAGS.single_process:
+        if FLAGS.job_name is None:
+            FLAGS.job_name = "worker"
+        if FLAGS.task_index is None:
+            FLAGS.task_index = 0
+    validate_role(FLAGS.job_name, FLAGS.task_index)                                        # :40-47
+    print('job_name : %s' % FLAGS.job_name)
+    print('task_index : %d' % FLAGS.task_index)
+
+    if FLAGS.single_process:
+        ps_spec, worker_spec = [], ["127.0.0.1:0"]
+    else:
+        ps_spec = split_hosts(FLAGS.ps_hosts)                                              # :49-50
+        worker_spec = split_hosts(FLAGS.worker_hosts)
+    num_workers = len(worker_spec)                                                         # :52
+    cluster = ClusterSpec({'ps': ps_spec, 'worker': worker_spec})                          # :53
+    role = Role(FLAGS.job_name, FLAGS.task_index, cluster)
+    device = resolve_device(role, FLAGS.device)
+    ps_backend = FLAGS.ps_backend if FLAGS.ps_backend != "auto" else "hbm"
+
+    if ps_backend == "host":
+        from .parallel import host_ps
+        return host_ps.run_role(role, device, datasets, FLAGS)
+
+    server = Server(cluster, FLAGS.job_name, FLAGS.task_index, ps_backend=ps_backend, device=device,
+                    dist_backend=FLAGS.dist_backend, start=not FLAGS.single_process)       # :54
+    if FLAGS.job_name == 'ps':
+        server.join()                                                                      # :55-56
+        return 0
+
+    is_chief = (FLAGS.task_index == 0)                                                     # :58
+    state, prog, engine, is_async = build_worker(
+        role, device, datasets, FLAGS.hidden_units, FLAGS.batch_size, FLAGS.learning_rate, FLAGS.sync_replicas,
+        FLAGS.replicas_to_aggregate, num_workers, FLAGS.task_index, optimizer=FLAGS.optimizer, loss=FLAGS.loss,
+        post_update_accuracy=FLAGS.post_update_accuracy, hidden_layers=FLAGS.hidden_layers, staleness=FLAGS.staleness,
+        num_ps=max(1, len(ps_spec)), seed=FLAGS.seed)
+
+    seed = FLAGS.seed if FLAGS.seed else (int(time.time() * 1000) & 0x7FFFFFFF)
+    sv = Supervisor(is_chief=is_chief, logdir=FLAGS.train_dir, init_fn=lambda: state.initialize(seed), state=state,
+                    recovery_wait_secs=1, save_model_secs=FLAGS.save_model_secs, store=server.store,
+                    group_size=num_workers)                                                # :108-111
+    if is_chief:
+        print('Worker %d: Initailizing session...' % FLAGS.task_index)                     # :122
+    else:
+        print('Worker %d: Waiting for session to be initaialized...' % FLAGS.task_index)   # :124
+    sv.prepare_or_wait_for_session()                                                       # :125
+    print('Worker %d: Session initialization  complete.' % FLAGS.task_index)               # :126
+
+    if FLAGS.sync_replicas and is_chief:
+        print('Starting chief queue runner and running init_tokens_op')                    # :129
+
+    val = (torch.from_numpy(datasets.validation.images).to(device), torch.from_numpy(datasets.validation.labels).to(device))
+    test = (torch.from_numpy(datasets.test.images).to(device), torch.from_numpy(datasets.test.labels).to(device))
+    loop = TrainingLoop(FLAGS.task_index, prog, engine, FLAGS.train_steps, FLAGS.validation_every, FLAGS.log_every,
+                        FLAGS.steps_per_launch, val, test, sv, is_async, num_workers)
+    train_time = loop.run()                                                                # :133-158
+    print('Training elapsed time:%f s' % train_time)                                       # :161
+    if is_async:
+        engine.sync_params()
+    test_accuracy = prog.accuracy(*test)                                                   # :163-164
+    print('Worker %d: test accuracy %g' % (FLAGS.task_index, test_accuracy))               # :165
+    examples = loop.local_step * FLAGS.batch_size
+    print('Worker %d: %d local steps, %.1f examples/sec on this worker' % (FLAGS.task_index, loop.local_step,
+                                                                           examples / max(train_time, 1e-9)))
+    if is_async:
+        engine.finish()
+    sv.stop()
+    server.shutdown()
+    sys.stdout.flush()
+    return 0
+
+
+def run() -> None:
+    """Entry point: ``tf.app.run()`` (distributed.py:167-168)."""
+    define_flags()
+    flags_lib.run(main)
