@@ -40,7 +40,7 @@ ALLREDUCE_BELOW_BYTES = 1 << 20
 class SyncReplicasEngine:
     def __init__(self, program, state: ShardedState, group=None, replicas_to_aggregate: Optional[int] = None,
                  total_num_replicas: Optional[int] = None, collective: str = "auto",
-                 arrival_delay: Optional[Callable[[int], float]] = None):
+                 arrival_delay: Optional[Callable[[int], float]] = None, force_collectives: bool = False):
         self.program, self.state = program, state
         self.world = state.world_size
         self.total = total_num_replicas if total_num_replicas is not None else self.world
@@ -49,7 +49,10 @@ class SyncReplicasEngine:
         self.R = replicas_to_aggregate if replicas_to_aggregate is not None else self.world
         if self.R <= 0:
             raise ValueError("replicas_to_aggregate must be positive")
-        self.coll = Collectives(group) if self.world > 1 else None
+        # force_collectives: issue the collectives even on a one-rank group (exercises the RCCL calls
+        # and their hipGraph capture on a single-GPU box)
+        self.use_coll = self.world > 1 or force_collectives
+        self.coll = Collectives(group) if self.use_coll else None
         if collective == "auto":
             small = state.nbytes() < ALLREDUCE_BELOW_BYTES and state.optimizer == "sgd"
             collective = "all_reduce" if small else "reduce_scatter"
@@ -59,7 +62,7 @@ class SyncReplicasEngine:
         self.fast = self.R == self.world
         self.arrival_delay = arrival_delay      # test hook: artificial per-step compute delay of this rank
         self._rs_out = torch.empty(state.layout.shard_size, dtype=torch.float32, device=state.device) \
-            if self.world > 1 else None
+            if self.use_coll else None
         self._acc = None
         self.updates_applied = 0
         self.dropped = 0                        # gradients of THIS rank that were discarded as late
@@ -71,7 +74,7 @@ class SyncReplicasEngine:
         if program.fused and not (self.fast and self.world == 1):
             raise ValueError("a program with the update fused into its epilogue only fits one rank with R == 1")
         if self.fast and not program.fused:
-            program.after_compute = self._aggregate_and_apply if self.world > 1 else (lambda: state.apply_shard(None, 1.0))
+            program.after_compute = self._aggregate_and_apply if self.use_coll else (lambda: state.apply_shard(None, 1.0))
 
     # ------------------------------------------------------------------ fast path (R == num_workers)
     def _aggregate_and_apply(self) -> None:
@@ -88,7 +91,7 @@ class SyncReplicasEngine:
     def run(self, n_steps: int, graph_steps: int = 64) -> None:
         """Run ``n_steps`` aggregated updates (each rank contributes as the R/num_workers ratio dictates)."""
         if self.fast:
-            if self.world > 1 and self.program.use_graphs:
+            if self.use_coll and self.program.use_graphs:
                 try:
                     self.program.run(n_steps, graph_steps)
                 except RuntimeError:

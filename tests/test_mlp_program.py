@@ -112,3 +112,54 @@ def test_gpu_trajectory_matches_cpu(hidden, post, graphs):
     xt, yt = torch.from_numpy(ds.test.images), torch.from_numpy(ds.test.labels)
     assert abs(prog_g.accuracy(xt.cuda(), yt.cuda()) - prog_c.accuracy(xt, yt)) < 0.01
     assert prog_g.post_correct_of_last_step() == prog_c.post_correct_of_last_step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("collective,optimizer", [("all_reduce", "sgd"), ("reduce_scatter", "sgd"), ("reduce_scatter", "adam")])
+def test_gpu_rccl_collectives_in_captured_step(collective, optimizer):
+    """One-rank RCCL group: the reduce-scatter / all-gather / all-reduce calls of the sync engine,
+    captured in the step hipGraph, must leave the trajectory identical to the fused local update."""
+    import torch.distributed as dist
+    from dist_utils import free_port
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    steps = 24
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=200, test_size=300, seed=5)
+
+    def make(fused, coll):
+        st = build_mlp_state(784, [100], 10, "cuda", lr=0.3 if optimizer == "sgd" else 1e-3, optimizer=optimizer)
+        st.initialize(seed=11)
+        prog = MLPProgram(st, DeviceDataset(ds.train, "cuda", shuffle_seed=5), 100, [100], fused_update=fused)
+        eng = SyncReplicasEngine(prog, st, collective=coll or "auto", force_collectives=coll is not None)
+        return st, prog, eng
+
+    st_a, prog_a, eng_a = make(optimizer == "sgd", None)
+    st_b, prog_b, eng_b = make(False, collective)
+    eng_a.run(steps, 8)
+    eng_b.run(steps, 8)
+    torch.cuda.synchronize()
+    ra, rb = prog_a.read_log(0, steps), prog_b.read_log(0, steps)
+    for a, b in zip(ra, rb):
+        assert abs(a.loss - b.loss) < 1e-5 and a.global_step == b.global_step
+    torch.testing.assert_close(st_a.params, st_b.params, rtol=1e-5, atol=1e-6)
+    assert st_b.global_step() == steps + 1
+
+
+@pytest.mark.gpu
+def test_gpu_cli_single_worker_runs_hip_path(capsys):
+    from distributed_tensorflow_amd import flags as F, train
+    from distributed_tensorflow_amd.ops import _lib
+    train.define_flags()
+    F.FLAGS.reset()
+    F.FLAGS.parse(["--single_process", "--synthetic_data", "--synthetic_train_size=3000", "--train_steps=300",
+                   "--learning_rate=0.5", "--seed=3", "--validation_every=100", "--device=gpu", "--save_model_secs=0"])
+    assert train.main([]) == 0
+    out = capsys.readouterr().out.splitlines()
+    steps = [l for l in out if "traing step" in l]
+    assert len(steps) == 300 and steps[-1].startswith("Worker 0: traing step 300 (global step:300)")
+    assert float(steps[-1].split("loss ")[1].split()[0]) < 1.6
+    assert sum("validation accuracy" in l for l in out) == 3
+    assert _lib._kernels is not None            # the HIP library did the work
+    F.FLAGS.reset()
