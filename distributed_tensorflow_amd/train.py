@@ -79,6 +79,7 @@ class TrainingLoop:
         self.records: List[StepRecord] = []      # everything printed, for callers that want the trajectory
         self.keep_records = False
         self.validation_accuracies: List[float] = []
+        self.stop_check = None                   # optional callable: True once the engine was told to stop
 
     def _print_record(self, r: StepRecord) -> None:
         if self.keep_records:
@@ -122,6 +123,11 @@ class TrainingLoop:
             n = self._plan(gs_seen)
             first = self.local_step
             self.engine.run(n, min(n, 64) if n >= 2 else 1)
+            if self.stop_check is not None and self.stop_check():
+                n = prog.steps_enqueued - first  # the service ended training: keep what actually ran
+                done = True
+                if n <= 0:
+                    break
             self.local_step += n
             recs = prog.read_log(first, n)       # synchronises with the device
             if held is not None:
