@@ -113,7 +113,9 @@ class PSClient:
         op_, on = (out.ctypes.data_as(C.c_void_p), out.nbytes) if out is not None else (None, 0)
         rc = _rt().dtf_ps_call(self._h, op, var, aux, value, scalar, pp, pn, op_, on, C.byref(self._nb),
                                C.byref(self._val), C.byref(self._aux))
-        if rc == STATUS_STOPPING:
+        if rc == STATUS_STOPPING or rc < 0:
+            # status 4: a blocked call was released by shutdown; negative: the connection is gone,
+            # which only happens once the chief has shut the service down
             raise PSStopped()
         if rc != 0:
             raise RuntimeError(f"parameter service call {op} failed with code {rc}")
@@ -265,7 +267,7 @@ class HostPSEngine:
         self._runner.start()
 
     # ------------------------------------------------------------------ end of training
-    def finish(self, grace_secs: float = 30.0) -> None:
+    def finish(self, grace_secs: float = 5.0) -> None:
         """Clean termination (the reference's ps never exits and its sync workers can hang when the
         chief leaves): every worker reports done; the chief waits for the others, then shuts the
         service down, which also releases anyone still blocked on a token."""
