@@ -42,6 +42,8 @@ struct DtfSmallGemmArgs {
   int lda, ldb, ldc, ldmask;
   int relu;
   int b_transposed;
+  unsigned a_bytes;         // bytes addressable from A / B (operands are read through 32-bit-offset buffer
+  unsigned b_bytes;         // descriptors: each must stay below 4 GiB)
 };
 
 #define DTF_MAX_WGRAD_PROBLEMS 8
@@ -57,6 +59,8 @@ struct DtfWgradProblem {
   int ldx, ldy, ldw;
   int tile_start;           // first linear tile id of this problem
   int tiles_n;
+  unsigned x_bytes;         // bytes addressable from X / dY
+  unsigned y_bytes;
 };
 
 struct DtfWgradArgs {
@@ -84,6 +88,8 @@ struct DtfHeadArgs {
   int ldh, ld_dz1;
   int loss_mode;            // 0: reference (softmax applied twice, distributed.py:81+86), 1: standard xent on logits
   float inv_b;
+  unsigned h_bytes;         // bytes addressable from Hact
+  int pad_;
 };
 
 DTF_EXPORT int dtf_small_gemm(const DtfSmallGemmArgs* a, hipStream_t s);

@@ -3,15 +3,26 @@
 //
 // The default workload is ~34 MFLOP and ~318 KB of parameters per step: it is
 // bound by launch count and dependency latency, not by FLOPs.  The step is
-// therefore three launches, each spread over many CUs with one 16x16 output
-// tile per wave, operands loaded straight from L2 into MFMA fragment layout
-// (no LDS round trip: nothing is re-used inside a workgroup), and the exact
-// fp32 matrix instruction v_mfma_f32_16x16x4_f32:
+// three launches, each spread over many CUs with one 16x16 output tile per
+// wave, operands loaded straight from L2 into MFMA fragment layout (nothing is
+// re-used inside a workgroup, so no LDS staging), and the exact fp32 matrix
+// instruction v_mfma_f32_16x16x4_f32:
 //
 //   1. small_gemm  : H = relu(X[rows] @ W1 + b1)          (split-K over the waves of a workgroup)
-//   2. head        : z2, y, softmax(y), loss, accuracy, dz2, dz1   (one wave per 16 rows, all in registers)
+//   2. head        : z2, y, softmax(y), loss, accuracy, dz2, dz1   (16 rows per workgroup, in registers)
 //   3. wgrad       : dW1, db1, dW2, db2 as one grouped launch; optionally theta -= lr*grad in the epilogue,
 //                    plus the step tail (counters, log record, next batch rows).
+//
+// What was measured while tuning these (hipGraph replay, MI355X):
+//   * An empty kernel costs 1.9 us per graph node.  A kernel's instruction stream is fetched cold
+//     after every kernel boundary, so its straight-line length is paid in latency: the same GEMM
+//     ran 4.2 us with an 8-chunk unrolled body and 2.6 us with a 1-chunk body at K = 64.
+//     Hence: short bodies, loops that re-execute cached code, few and wide memory instructions.
+//   * `ok ? *p : 0` becomes a branch with its own s_waitcnt and serialises a batch of loads.
+//     All operand loads are therefore raw buffer loads: the hardware range check returns 0 for an
+//     out-of-range offset, so guards are a select on a 32-bit offset, never a branch.
+//   * Reductions over the 16 classes use DPP row rotations (one VALU op per step) instead of
+//     ds_bpermute shuffles.
 //
 // Fragment maps of v_mfma_f32_16x16x4_f32 (lane l, fr = l & 15, g = l >> 4):
 //   A operand: A[m = fr][k = g]     B operand: B[k = g][n = fr]
@@ -20,25 +31,59 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// Out-of-range operand elements are read from this zero block instead of being guarded:
-// `ok ? *p : 0` is compiled into a branch around the load with its own s_waitcnt, which
-// serialises a batch of loads that must all be in flight together (these kernels are
-// latency bound).  Selecting the ADDRESS keeps every load unconditional.
-__device__ float4 dtf_zero16[2];
-__device__ __forceinline__ float ld_or_zero(const float* p, bool ok) {
-  return *(ok ? p : reinterpret_cast<const float*>(dtf_zero16));
+// ---- raw buffer access: byte offsets, out-of-range -> 0 -------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+static constexpr unsigned kOOB = 0xFFFFFFF0u;   // beyond any num_records: the load returns 0
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
-  return *reinterpret_cast<const float4*>(ok ? p : reinterpret_cast<const float*>(dtf_zero16));
+__device__ __forceinline__ float bld(rsrc_t r, unsigned off) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }
-__device__ __forceinline__ int ldi_or_zero(const int* p, bool ok) {
-  return *(ok ? p : reinterpret_cast<const int*>(dtf_zero16));
+__device__ __forceinline__ int bldi(rsrc_t r, unsigned off) { return (int)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0); }
+__device__ __forceinline__ void bld4(rsrc_t r, unsigned off, float (&v)[4]) {
+  auto t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  v[0] = __uint_as_float(t[0]); v[1] = __uint_as_float(t[1]); v[2] = __uint_as_float(t[2]); v[3] = __uint_as_float(t[3]);
 }
 
+// ---- reductions over a 16-lane row by DPP rotation (every lane ends with the result) ---------------
+#define DTF_ROR(v, n) __builtin_amdgcn_update_dpp((v), (v), 0x120 + (n), 0xf, 0xf, false)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += DTF_ROR(v, 8); v += DTF_ROR(v, 4); v += DTF_ROR(v, 2); v += DTF_ROR(v, 1);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, DTF_ROR(v, 8)); v = fmaxf(v, DTF_ROR(v, 4)); v = fmaxf(v, DTF_ROR(v, 2)); v = fmaxf(v, DTF_ROR(v, 1));
+  return v;
+}
+__device__ __forceinline__ int row16_min(int v) {
+  v = min(v, DTF_ROR(v, 8)); v = min(v, DTF_ROR(v, 4)); v = min(v, DTF_ROR(v, 2)); v = min(v, DTF_ROR(v, 1));
+  return v;
+}
+
+// Diagnostic build only (-DDTF_STAMPS): per-workgroup timestamps of the 100 MHz constant clock,
+// written to a buffer of their own.  No stamp executes in the production library.
+#ifdef DTF_STAMPS
+__device__ unsigned long long* dtf_stamp_buf = nullptr;
+#define DTF_STAMP(slot, wg)                                                                                             \
+  do {                                                                                                                  \
+    if (threadIdx.x == 0 && dtf_stamp_buf) dtf_stamp_buf[(size_t)(wg) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+extern "C" __attribute__((visibility("default"))) int dtf_set_stamp_buffer(unsigned long long* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dtf_stamp_buf), &p, sizeof(p));
+}
+__global__ void stamp_now_kernel(unsigned long long* out) { *out = __builtin_amdgcn_s_memrealtime(); }
+extern "C" __attribute__((visibility("default"))) int dtf_stamp_now(unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(stamp_now_kernel, dim3(1), dim3(1), 0, s, out);
+  return 0;
+}
+#else
+#define DTF_STAMP(slot, wg) do { } while (0)
+#endif
+
 // --------------------------------------------------------------------------------------
-// step tail
+// step tail.  Runs in ONE workgroup of exactly 256 threads.
 // --------------------------------------------------------------------------------------
-// Runs in ONE workgroup of exactly 256 threads.
 __device__ __forceinline__ void dtf_tail_body(const DtfTailArgs& t, int tid, int nthreads, bool init_only) {
   __shared__ float s_loss[256];
   __shared__ int s_cnt[256][2];
@@ -108,7 +153,12 @@ DTF_EXPORT int dtf_step_tail(const DtfTailArgs* a, int init_only, hipStream_t s)
 
 // --------------------------------------------------------------------------------------
 // small GEMM:  C = epilogue(A[rows] @ B)   with B either [K,N] or (NT) [N,K]
+// One 16x16 tile per workgroup; the NW waves split K round-robin in 16-deep chunks.
 // --------------------------------------------------------------------------------------
+#ifndef DTF_GEMM_CH
+#define DTF_GEMM_CH 4
+#endif
+
 template <int NW, bool BT, bool VEC>
 __global__ __launch_bounds__(NW * 64) void small_gemm_kernel(DtfSmallGemmArgs p) {
   __shared__ float red[NW][4][64];
@@ -116,51 +166,52 @@ __global__ __launch_bounds__(NW * 64) void small_gemm_kernel(DtfSmallGemmArgs p)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, and provably so
   const int fr = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int wg_id = blockIdx.y * gridDim.x + blockIdx.x;
+  (void)wg_id;
+  DTF_STAMP(0, wg_id);
 
+  const rsrc_t ra = make_rsrc(p.A, p.a_bytes), rb = make_rsrc(p.B, p.b_bytes);
   const int arow = m0 + fr;
   const bool arow_ok = arow < p.M;
-  const int asrc = p.a_rows ? ldi_or_zero(p.a_rows + arow, arow_ok) : (arow_ok ? arow : 0);
-  const float* __restrict__ aptr = p.A + (size_t)asrc * p.lda;
+  const int asrc = p.a_rows ? p.a_rows[arow_ok ? arow : 0] : arow;
+  const unsigned a_row_off = arow_ok ? (unsigned)asrc * (unsigned)p.lda * 4u : kOOB;
   const int bcol = n0 + fr;
   const bool bcol_ok = bcol < p.N;
-  const float* __restrict__ bptr = BT ? p.B + (size_t)(bcol_ok ? bcol : 0) * p.ldb : p.B + (bcol_ok ? bcol : 0);
+  const unsigned b_lane_off = bcol_ok ? (BT ? (unsigned)bcol * (unsigned)p.ldb * 4u : (unsigned)bcol * 4u) : kOOB;
 
-  // Epilogue operands of the element this thread will finish (e = threadIdx.x, first 256 threads)
-  // are requested before the main loop so their latency is not paid after the reduction.
+  // Epilogue operands of the element this thread will finish (first 256 threads) are requested
+  // before the main loop so their latency is not paid after the reduction.
   const int e_r = (threadIdx.x >> 6) & 3, e_ln = threadIdx.x & 63;
   const int e_row = m0 + 4 * (e_ln >> 4) + e_r, e_col = n0 + (e_ln & 15);
   const bool e_ok = threadIdx.x < 256 && e_row < p.M && e_col < p.N;
-  const float e_bias = p.bias ? ld_or_zero(p.bias + e_col, e_ok) : 0.f;
-  const float e_mask = p.mask ? ld_or_zero(p.mask + (size_t)e_row * p.ldmask + e_col, e_ok) : 1.f;
+  const float e_bias = (p.bias && e_ok) ? p.bias[e_col] : 0.f;
+  const float e_mask = (p.mask && e_ok) ? p.mask[(size_t)e_row * p.ldmask + e_col] : 1.f;
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const int nchunk = (p.K + 15) >> 4;
-  // The kernel is latency bound: issue the operand loads of CH k-chunks back to back (fully
-  // unrolled, guards are predicates not branches), then run their MFMAs.
-  constexpr int CH = 8;
+  constexpr int CH = DTF_GEMM_CH;
   for (int cb = wave; cb < nchunk; cb += NW * CH) {
     float av[CH][4], bv[CH][4];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int k = ((cb + i * NW) << 4) + 4 * g;
+      const int k = ((cb + i * NW) << 4) + 4 * g;   // chunks past the end: every k >= K, every offset out of range
       if (VEC) {
-        const float4 t = ld4_or_zero(aptr + k, arow_ok && k < p.K);
-        av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+        bld4(ra, (a_row_off != kOOB && k < p.K) ? a_row_off + (unsigned)k * 4u : kOOB, av[i]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) av[i][j] = ld_or_zero(aptr + k + j, arow_ok && k + j < p.K);
+        for (int j = 0; j < 4; ++j) av[i][j] = bld(ra, (a_row_off != kOOB && k + j < p.K) ? a_row_off + (unsigned)(k + j) * 4u : kOOB);
       }
       if (BT) {
         if (VEC) {
-          const float4 t = ld4_or_zero(bptr + k, bcol_ok && k < p.K);
-          bv[i][0] = t.x; bv[i][1] = t.y; bv[i][2] = t.z; bv[i][3] = t.w;
+          bld4(rb, (b_lane_off != kOOB && k < p.K) ? b_lane_off + (unsigned)k * 4u : kOOB, bv[i]);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bv[i][j] = ld_or_zero(bptr + k + j, bcol_ok && k + j < p.K);
+          for (int j = 0; j < 4; ++j) bv[i][j] = bld(rb, (b_lane_off != kOOB && k + j < p.K) ? b_lane_off + (unsigned)(k + j) * 4u : kOOB);
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[i][j] = ld_or_zero(bptr + (size_t)(k + j) * p.ldb, bcol_ok && k + j < p.K);
+        for (int j = 0; j < 4; ++j)
+          bv[i][j] = bld(rb, (b_lane_off != kOOB && k + j < p.K) ? b_lane_off + (unsigned)(k + j) * (unsigned)p.ldb * 4u : kOOB);
       }
     }
 #pragma unroll
@@ -171,35 +222,35 @@ __global__ __launch_bounds__(NW * 64) void small_gemm_kernel(DtfSmallGemmArgs p)
       acc1 = MFMA16(av[i][3], bv[i][3], acc1);
     }
   }
+  DTF_STAMP(1, wg_id);
+  if (NW == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 4 * g + r;
+      if (row < p.M && bcol_ok) {
+        float s = acc0[r] + acc1[r];
+        if (p.bias) s += p.bias[bcol];
+        if (p.relu) s = fmaxf(s, 0.f);
+        if (p.mask) s = p.mask[(size_t)row * p.ldmask + bcol] > 0.f ? s : 0.f;
+        p.C[(size_t)row * p.ldc + bcol] = s;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
   __syncthreads();
-  if (NW >= 4) {
-    if (e_ok) {
-      float s = 0.f;
+  DTF_STAMP(2, wg_id);
+  if (e_ok) {
+    float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) s += red[w][e_r][e_ln];
-      s += e_bias;
-      if (p.relu) s = fmaxf(s, 0.f);
-      s = e_mask > 0.f ? s : 0.f;
-      p.C[(size_t)e_row * p.ldc + e_col] = s;
-    }
-  } else {
-    for (int e = threadIdx.x; e < 256; e += NW * 64) {
-      const int r = e >> 6, ln = e & 63;
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) s += red[w][r][ln];
-      const int row = m0 + 4 * (ln >> 4) + r;
-      const int col = n0 + (ln & 15);
-      if (row < p.M && col < p.N) {
-        if (p.bias) s += p.bias[col];
-        if (p.relu) s = fmaxf(s, 0.f);
-        if (p.mask) s = p.mask[(size_t)row * p.ldmask + col] > 0.f ? s : 0.f;
-        p.C[(size_t)row * p.ldc + col] = s;
-      }
-    }
+    for (int w = 0; w < NW; ++w) s += red[w][e_r][e_ln];
+    s += e_bias;
+    if (p.relu) s = fmaxf(s, 0.f);
+    s = e_mask > 0.f ? s : 0.f;
+    p.C[(size_t)e_row * p.ldc + e_col] = s;
   }
+  DTF_STAMP(3, wg_id);
 }
 
 template <int NW>
@@ -222,21 +273,32 @@ DTF_EXPORT int dtf_small_gemm(const DtfSmallGemmArgs* a, hipStream_t s) {
   if (a->b_transposed ? a->ldb < a->K : a->ldb < a->N) return DTF_ERR_SHAPE;
   if (a->mask && a->ldmask < a->N) return DTF_ERR_SHAPE;
   if (dtf_cdiv(a->M, 16) > 65535) return DTF_ERR_SHAPE;
-  // float4 operand loads need 16-byte aligned rows; otherwise take the scalar-load build.
+  // operands are addressed with 32-bit byte offsets through buffer descriptors
+  if (a->a_bytes == 0 || a->b_bytes == 0 || a->a_bytes >= kOOB || a->b_bytes >= kOOB) return DTF_ERR_SHAPE;
+  if (!a->a_rows && (uint64_t)((uint64_t)(a->M - 1) * a->lda + a->K) * 4u > a->a_bytes) return DTF_ERR_SHAPE;
+  const uint64_t b_need = a->b_transposed ? ((uint64_t)(a->N - 1) * a->ldb + a->K) : ((uint64_t)(a->K - 1) * a->ldb + a->N);
+  if (b_need * 4u > a->b_bytes) return DTF_ERR_SHAPE;
+  // 16-byte operand loads need 16-byte aligned rows; otherwise take the dword-load build.
   bool vec = (a->K % 4 == 0) && (a->lda % 4 == 0) && dtf_aligned16(a->A);
   if (a->b_transposed) vec = vec && (a->ldb % 4 == 0) && dtf_aligned16(a->B);
-  // Deep reductions get 8 waves per tile so the dependent MFMA chain stays short.
-  if (a->K >= 512) return launch_small_gemm<8>(*a, vec, s);
+  // Deep reductions get more waves per tile so that each wave runs the loop body once or twice.
+  if (a->K >= 512) return launch_small_gemm<16>(*a, vec, s);
+  if (a->K >= 192) return launch_small_gemm<8>(*a, vec, s);
   if (a->K >= 64) return launch_small_gemm<4>(*a, vec, s);
   return launch_small_gemm<1>(*a, vec, s);
 }
 
 // --------------------------------------------------------------------------------------
 // grouped weight gradient:  dW = X[rows]^T @ dY,  db = colsum(dY)   (+ fused SGD, + step tail)
+// One 16x16 tile per wave, four tiles per workgroup; one extra workgroup runs the step tail.
 // --------------------------------------------------------------------------------------
+#ifndef DTF_WGRAD_CH
+#define DTF_WGRAD_CH 4
+#endif
+
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
   const int nblk_tiles = (p.total_tiles + 3) >> 2;
-  if ((int)blockIdx.x >= nblk_tiles) {  // one extra workgroup runs the step tail
+  if ((int)blockIdx.x >= nblk_tiles) {
     if (p.tail.enable) dtf_tail_body(p.tail, threadIdx.x, blockDim.x, false);
     return;
   }
@@ -258,9 +320,11 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
   const bool am_ok = am < q.Mo;
   const int bn = n0 + fr;
   const bool bn_ok = bn < q.N;
-  const float* __restrict__ X = q.X;
-  const float* __restrict__ dY = q.dY;
-  const int* __restrict__ xrows = q.x_rows;
+  const rsrc_t rx = make_rsrc(q.X, q.x_bytes), ry = make_rsrc(q.dY, q.y_bytes);
+  const bool gather = q.x_rows != nullptr;
+  const rsrc_t rr = make_rsrc(gather ? (const void*)q.x_rows : (const void*)q.X, gather ? (unsigned)q.Kb * 4u : 0u);
+  const unsigned a_lane = (unsigned)am * 4u;
+  const unsigned b_lane = (unsigned)bn * 4u;
 
   // fused update: the old parameter values are requested up front, not after the MFMA chain
   float wold[4] = {0.f, 0.f, 0.f, 0.f};
@@ -269,13 +333,13 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 4 * g + r;
-      wold[r] = ld_or_zero(q.W + (size_t)row * q.ldw + bn, row < q.Mo && bn_ok);
+      if (row < q.Mo && bn_ok) wold[r] = q.W[(size_t)row * q.ldw + bn];
     }
-    bold = ld_or_zero(q.b + bn, bn_ok);
+    if (tm == 0 && g == 0 && bn_ok) bold = q.b[bn];
   }
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  constexpr int CH = 8;   // 128 batch rows per pass: row indices, then every operand load, then the MFMAs
+  constexpr int CH = DTF_WGRAD_CH;   // 16*CH batch rows per pass: row indices, then every operand load, then the MFMAs
   for (int kb = 0; kb < q.Kb; kb += 16 * CH) {
     int xr[CH][4];
     float av[CH][4], bv[CH][4];
@@ -284,7 +348,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k = kb + 16 * i + 4 * j + g;
-        xr[i][j] = xrows ? ldi_or_zero(xrows + k, k < q.Kb) : k;
+        xr[i][j] = gather ? bldi(rr, (unsigned)k * 4u) : k;   // k >= Kb reads 0 (the descriptor holds Kb entries)
       }
 #pragma unroll
     for (int i = 0; i < CH; ++i)
@@ -292,8 +356,8 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
       for (int j = 0; j < 4; ++j) {
         const int k = kb + 16 * i + 4 * j + g;
         const bool kok = k < q.Kb;
-        av[i][j] = ld_or_zero(X + (size_t)xr[i][j] * q.ldx + am, kok && am_ok);
-        bv[i][j] = ld_or_zero(dY + (size_t)k * q.ldy + bn, kok && bn_ok);
+        av[i][j] = bld(rx, (kok && am_ok) ? (unsigned)xr[i][j] * (unsigned)q.ldx * 4u + a_lane : kOOB);
+        bv[i][j] = bld(ry, (kok && bn_ok) ? (unsigned)k * (unsigned)q.ldy * 4u + b_lane : kOOB);
       }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -334,6 +398,9 @@ DTF_EXPORT int dtf_wgrad_grouped(const DtfWgradArgs* a, hipStream_t s) {
     if (q.Mo <= 0 || q.N <= 0 || q.Kb <= 0) return DTF_ERR_SHAPE;
     if (q.ldx < q.Mo || q.ldy < q.N || q.ldw < q.N) return DTF_ERR_SHAPE;
     if (q.tiles_n != dtf_cdiv(q.N, 16) || q.tile_start != tiles) return DTF_ERR_SHAPE;
+    if (q.x_bytes == 0 || q.y_bytes == 0 || q.x_bytes >= kOOB || q.y_bytes >= kOOB) return DTF_ERR_SHAPE;
+    if (!q.x_rows && ((uint64_t)(q.Kb - 1) * q.ldx + q.Mo) * 4u > q.x_bytes) return DTF_ERR_SHAPE;
+    if (((uint64_t)(q.Kb - 1) * q.ldy + q.N) * 4u > q.y_bytes) return DTF_ERR_SHAPE;
     tiles += q.tiles_n * dtf_cdiv(q.Mo, 16);
   }
   if (tiles != a->total_tiles) return DTF_ERR_SHAPE;
@@ -348,38 +415,17 @@ DTF_EXPORT int dtf_wgrad_grouped(const DtfWgradArgs* a, hipStream_t s) {
 }
 
 // --------------------------------------------------------------------------------------
-// head: logits, (double) softmax cross-entropy, accuracy, dz2 and dz1 for 16 rows per wave
-// --------------------------------------------------------------------------------------
-__device__ __forceinline__ float group16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1));
-  v = fmaxf(v, __shfl_xor(v, 2));
-  v = fmaxf(v, __shfl_xor(v, 4));
-  v = fmaxf(v, __shfl_xor(v, 8));
-  return v;
-}
-__device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
-  return v;
-}
-// argmax with lowest-index tie break (tf.argmax semantics, distributed.py:83)
-__device__ __forceinline__ int group16_argmax(float v, int idx) {
-#pragma unroll
-  for (int m = 1; m < 16; m <<= 1) {
-    const float ov = __shfl_xor(v, m);
-    const int oi = __shfl_xor(idx, m);
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
-  return idx;
-}
-
+// head: logits, (double) softmax cross-entropy, accuracy, dz2 and dz1.
 // One workgroup = 4 waves = 16 rows.  The three dependent phases are each split over the
 // four waves so that the serial latency chain per wave stays short:
 //   A  z2 partial sums, k-chunks dealt round-robin to the waves (reduced through LDS)
 //   B  wave w does the softmax / loss / accuracy / dz2 math of rows 4g + w
 //   C  dz1 column chunks dealt round-robin to the waves
+// --------------------------------------------------------------------------------------
+#ifndef DTF_HEAD_CH
+#define DTF_HEAD_CH 2
+#endif
+
 __global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
   __shared__ float red[4][4][64];
   __shared__ float dzs[16][17];
@@ -394,32 +440,14 @@ __global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
   const bool cls_ok = fr < C;
   const bool train_tile = r0 < p.M_train && p.dz1 != nullptr;   // workgroup-uniform
   const int nchunk = (Hd + 15) >> 4;
-  constexpr int CH = 4;
-
-  // ---- phase C operands of the first pass are requested first: they depend on nothing ----
-  float cw[CH][4], cact[CH][4];
-  auto load_c = [&](int cb) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int hcol = ((cb + 4 * i) << 4) + fr;
-      const bool h_ok = hcol < Hd;
-      const float* __restrict__ w2r = p.W2 + (size_t)hcol * C;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) cw[i][j] = ld_or_zero(w2r + 4 * j + g, h_ok && 4 * j + g < C);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + 4 * g + r;
-        cact[i][r] = ld_or_zero(p.Hact + (size_t)row * p.ldh + hcol, h_ok && row < p.M_train);
-      }
-    }
-  };
-  if (train_tile) load_c(wave);
+  constexpr int CH = DTF_HEAD_CH;
+  const rsrc_t rh = make_rsrc(p.Hact, p.h_bytes), rw = make_rsrc(p.W2, (unsigned)Hd * (unsigned)C * 4u);
 
   // ---- phase A: z2 = Hact @ W2 (16 rows x 16 padded classes), split-K over the waves ----
   const int arow = r0 + fr;
   const bool arow_ok = arow < p.M_total;
-  const float* __restrict__ hp = p.Hact + (size_t)arow * p.ldh;
-  const float* __restrict__ wp = p.W2 + fr;
+  const unsigned a_row_off = (unsigned)arow * (unsigned)p.ldh * 4u;
+  const unsigned b_lane_off = (unsigned)fr * 4u;
   const bool vec = ((p.ldh | Hd) & 3) == 0;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   for (int cb = wave; cb < nchunk; cb += 4 * CH) {
@@ -428,14 +456,13 @@ __global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
     for (int i = 0; i < CH; ++i) {
       const int k = ((cb + 4 * i) << 4) + 4 * g;
       if (vec) {
-        const float4 t = ld4_or_zero(hp + k, arow_ok && k < Hd);
-        av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+        bld4(rh, (arow_ok && k < Hd) ? a_row_off + (unsigned)k * 4u : kOOB, av[i]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) av[i][j] = ld_or_zero(hp + k + j, arow_ok && k + j < Hd);
+        for (int j = 0; j < 4; ++j) av[i][j] = bld(rh, (arow_ok && k + j < Hd) ? a_row_off + (unsigned)(k + j) * 4u : kOOB);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[i][j] = ld_or_zero(wp + (size_t)(k + j) * C, cls_ok && k + j < Hd);
+      for (int j = 0; j < 4; ++j) bv[i][j] = bld(rw, (cls_ok && k + j < Hd) ? (unsigned)(k + j) * (unsigned)C * 4u + b_lane_off : kOOB);
     }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -451,9 +478,10 @@ __global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
   const int row = r0 + 4 * g + wave;            // the one row this lane group handles in phase B
   const bool row_ok = row < p.M_total;
   const bool train_row = row < p.M_train;
-  const int lrow = p.rows ? ldi_or_zero(p.rows + row, row_ok) : row;
-  const float lab = ld_or_zero(p.labels + (size_t)lrow * C + fr, row_ok && cls_ok);
-  const float bias = ld_or_zero(p.b2 + fr, cls_ok);
+  const int lrow = p.rows ? p.rows[row_ok ? row : 0] : row;
+  const float labv = p.labels[(size_t)(row_ok ? lrow : 0) * C + (cls_ok ? fr : 0)];
+  const float lab = (row_ok && cls_ok) ? labv : 0.f;
+  const float biasv = p.b2[cls_ok ? fr : 0];
   __syncthreads();
 
   // ---- phase B ----
@@ -461,30 +489,32 @@ __global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
   int correct_acc = 0, post_acc = 0;
   {
     const float zsum = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
-    const float z = cls_ok ? zsum + bias : NEG_INF;
-    const float zmax = group16_max(z);
-    const float e1 = cls_ok ? expf(z - zmax) : 0.f;
-    const float s1 = group16_sum(e1);
+    const float z = cls_ok ? zsum + biasv : NEG_INF;
+    const float zmax = row16_max(z);
+    const float e1 = cls_ok ? __expf(z - zmax) : 0.f;
+    const float s1 = row16_sum(e1);
     const float y = e1 / s1;
     if (p.probs && row_ok && cls_ok) p.probs[(size_t)row * C + fr] = y;
     float logp, dz;
     if (p.loss_mode == 0) {
       // softmax applied a second time on the probabilities (the reference feeds y as "logits")
-      const float ymax = group16_max(cls_ok ? y : NEG_INF);
-      const float e2 = cls_ok ? expf(y - ymax) : 0.f;
-      const float s2 = group16_sum(e2);
+      const float ymax = row16_max(cls_ok ? y : NEG_INF);
+      const float e2 = cls_ok ? __expf(y - ymax) : 0.f;
+      const float s2 = row16_sum(e2);
       const float pp = e2 / s2;
-      logp = (y - ymax) - logf(s2);
+      logp = (y - ymax) - __logf(s2);
       const float dy = (pp - lab) * p.inv_b;
-      const float dot = group16_sum(cls_ok ? dy * y : 0.f);
+      const float dot = row16_sum(cls_ok ? dy * y : 0.f);
       dz = (dy - dot) * y;
     } else {
-      logp = (z - zmax) - logf(s1);
+      logp = (z - zmax) - __logf(s1);
       dz = (y - lab) * p.inv_b;
     }
-    const float lrow_loss = -group16_sum(cls_ok ? lab * logp : 0.f);
-    const int am_y = group16_argmax(cls_ok ? y : NEG_INF, fr);
-    const int am_l = group16_argmax(cls_ok ? lab : NEG_INF, fr);
+    const float lrow_loss = -row16_sum(cls_ok ? lab * logp : 0.f);
+    // argmax with lowest-index tie break (tf.argmax, distributed.py:83)
+    const int am_y = row16_min((cls_ok && z == zmax) ? fr : 16);
+    const float labmax = row16_max(cls_ok ? lab : NEG_INF);
+    const int am_l = row16_min((cls_ok && lab == labmax) ? fr : 16);
     const int hit = (row_ok && am_y == am_l) ? 1 : 0;
     if (fr == 0) {
       if (train_row) { loss_acc = lrow_loss; correct_acc = hit; }
@@ -519,7 +549,20 @@ __global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) a4[j] = dzs[fr][4 * j + g];
   for (int cb = wave; cb < nchunk; cb += 4 * CH) {
-    if (cb != wave) load_c(cb);
+    float cw[CH][4], cact[CH][4];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int hcol = ((cb + 4 * i) << 4) + fr;
+      const bool h_ok = hcol < Hd;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        cw[i][j] = bld(rw, (h_ok && 4 * j + g < C) ? ((unsigned)hcol * (unsigned)C + (unsigned)(4 * j + g)) * 4u : kOOB);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = r0 + 4 * g + r;
+        cact[i][r] = bld(rh, (h_ok && orow < p.M_train) ? ((unsigned)orow * (unsigned)p.ldh + (unsigned)hcol) * 4u : kOOB);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int hcol = ((cb + 4 * i) << 4) + fr;
@@ -544,6 +587,8 @@ DTF_EXPORT int dtf_head(const DtfHeadArgs* a, hipStream_t s) {
   if (a->C <= 0 || a->C > 16 || a->Hd <= 0 || a->ldh < a->Hd) return DTF_ERR_SHAPE;
   if (a->M_train > 0 && a->dz1 && a->ld_dz1 < a->Hd) return DTF_ERR_SHAPE;
   if (((a->ldh | a->Hd) & 3) == 0 && !dtf_aligned16(a->Hact)) return DTF_ERR_ALIGN;
+  if (a->h_bytes == 0 || a->h_bytes >= kOOB || ((uint64_t)(a->M_total - 1) * a->ldh + a->Hd) * 4u > a->h_bytes) return DTF_ERR_SHAPE;
+  if ((uint64_t)a->Hd * a->C * 4u >= kOOB) return DTF_ERR_SHAPE;
   hipLaunchKernelGGL(head_kernel, dim3(dtf_cdiv(a->M_total, 16)), dim3(256), 0, s, *a);
   return dtf_check_launch();
 }

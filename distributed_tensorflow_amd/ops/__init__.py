@@ -65,7 +65,8 @@ def linear_fwd(x, w, b=None, relu=False, rows=None, out=None, m=None):
     a = _lib.SmallGemmArgs(A=_f32c(x, "x").data_ptr(), a_rows=_lib.ptr(None if rows is None else _i32c(rows, "rows")),
                            B=_f32c(w, "w").data_ptr(), bias=_lib.ptr(None if b is None else _f32c(b, "b")), mask=None,
                            C=_f32c(out, "out").data_ptr(), M=M, N=N, K=K, lda=x.stride(0), ldb=w.stride(0),
-                           ldc=out.stride(0), ldmask=0, relu=int(bool(relu)), b_transposed=0)
+                           ldc=out.stride(0), ldmask=0, relu=int(bool(relu)), b_transposed=0,
+                           a_bytes=_lib.span_bytes(x), b_bytes=_lib.span_bytes(w))
     if b is not None and b.numel() != N:
         raise ValueError("linear_fwd: bias size mismatch")
     _lib.check(_lib.kernels().dtf_small_gemm(C.byref(a), _lib.stream_handle()), "linear_fwd")
@@ -94,7 +95,8 @@ def linear_bwd_data(dy, w, act=None, out=None, m=None):
     a = _lib.SmallGemmArgs(A=_f32c(dy, "dy").data_ptr(), a_rows=None, B=_f32c(w, "w").data_ptr(), bias=None,
                            mask=_lib.ptr(None if act is None else _f32c(act, "act")), C=_f32c(out, "out").data_ptr(),
                            M=M, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0),
-                           ldmask=0 if act is None else act.stride(0), relu=0, b_transposed=1)
+                           ldmask=0 if act is None else act.stride(0), relu=0, b_transposed=1,
+                           a_bytes=_lib.span_bytes(dy), b_bytes=_lib.span_bytes(w))
     _lib.check(_lib.kernels().dtf_small_gemm(C.byref(a), _lib.stream_handle()), "linear_bwd_data")
     return out
 
@@ -153,6 +155,7 @@ def build_wgrad_args(items, lr=None, tail=None):
         p.ldx, p.ldy, p.ldw = it.x.stride(0), it.dy.stride(0), tgt_w.stride(0)
         p.tile_start = tiles
         p.tiles_n = (n + 15) // 16
+        p.x_bytes, p.y_bytes = _lib.span_bytes(it.x), _lib.span_bytes(it.dy)
         tiles += p.tiles_n * ((mo + 15) // 16)
     args.nprob = len(items)
     args.total_tiles = tiles
@@ -216,7 +219,8 @@ def build_head_args(hact, w2, b2, labels, m_total, m_train, loss_mode, rows=None
                          dz1=_lib.ptr(dz1), probs=_lib.ptr(probs), loss_part=_lib.ptr(loss_part),
                          correct_part=_lib.ptr(correct_part), post_part=_lib.ptr(post_part), M_total=m_total,
                          M_train=m_train, Hd=hd, C=c, ldh=hact.stride(0), ld_dz1=0 if dz1 is None else dz1.stride(0),
-                         loss_mode=loss_mode, inv_b=(1.0 / m_train) if m_train else 0.0)
+                         loss_mode=loss_mode, inv_b=(1.0 / m_train) if m_train else 0.0,
+                         h_bytes=_lib.span_bytes(hact), pad_=0)
 
 
 def head(hact, w2, b2, labels, m_total, m_train, loss_mode=LOSS_REFERENCE, rows=None, dz2=None, dz1=None, probs=None,

@@ -37,7 +37,8 @@ class TailArgs(C.Structure):
 class SmallGemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("a_rows", C.c_void_p), ("B", C.c_void_p), ("bias", C.c_void_p), ("mask", C.c_void_p),
                 ("C", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int),
-                ("ldc", C.c_int), ("ldmask", C.c_int), ("relu", C.c_int), ("b_transposed", C.c_int)]
+                ("ldc", C.c_int), ("ldmask", C.c_int), ("relu", C.c_int), ("b_transposed", C.c_int),
+                ("a_bytes", C.c_uint), ("b_bytes", C.c_uint)]
 
 
 MAX_WGRAD_PROBLEMS = 8
@@ -46,7 +47,8 @@ MAX_WGRAD_PROBLEMS = 8
 class WgradProblem(C.Structure):
     _fields_ = [("X", C.c_void_p), ("x_rows", C.c_void_p), ("dY", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p),
                 ("W", C.c_void_p), ("b", C.c_void_p), ("Mo", C.c_int), ("N", C.c_int), ("Kb", C.c_int), ("ldx", C.c_int),
-                ("ldy", C.c_int), ("ldw", C.c_int), ("tile_start", C.c_int), ("tiles_n", C.c_int)]
+                ("ldy", C.c_int), ("ldw", C.c_int), ("tile_start", C.c_int), ("tiles_n", C.c_int),
+                ("x_bytes", C.c_uint), ("y_bytes", C.c_uint)]
 
 
 class WgradArgs(C.Structure):
@@ -59,7 +61,19 @@ class HeadArgs(C.Structure):
                 ("dz2", C.c_void_p), ("dz1", C.c_void_p), ("probs", C.c_void_p), ("loss_part", C.c_void_p),
                 ("correct_part", C.c_void_p), ("post_part", C.c_void_p), ("M_total", C.c_int), ("M_train", C.c_int),
                 ("Hd", C.c_int), ("C", C.c_int), ("ldh", C.c_int), ("ld_dz1", C.c_int), ("loss_mode", C.c_int),
-                ("inv_b", C.c_float)]
+                ("inv_b", C.c_float), ("h_bytes", C.c_uint), ("pad_", C.c_int)]
+
+
+def span_bytes(t) -> int:
+    """Bytes addressable from ``t.data_ptr()`` for a row-major 2-D (or 1-D) tensor view."""
+    if t.dim() == 1:
+        n = t.shape[0]
+    else:
+        n = (t.shape[0] - 1) * t.stride(0) + t.shape[1]
+    b = n * t.element_size()
+    if b >= 0xFFFFFFF0:
+        raise ValueError("operand of a small-MLP kernel must stay below 4 GiB (32-bit buffer offsets)")
+    return b
 
 
 def lib_path(name: str) -> str:
@@ -92,7 +106,8 @@ def kernels():
     if _kernels is None:
         with _lock:
             if _kernels is None:
-                path = lib_path("libdtf_kernels.so")
+                # DTF_KERNELS_LIB selects another build of the same ABI (the stamped diagnostic library)
+                path = os.environ.get("DTF_KERNELS_LIB") or lib_path("libdtf_kernels.so")
                 if not os.path.exists(path):
                     raise NativeLibraryMissing(
                         f"{path} not found: build it with `make -C distributed_tensorflow_amd/csrc` "
