@@ -92,6 +92,30 @@ struct DtfHeadArgs {
   int pad_;
 };
 
+// C[M,N] = A[M,K] . B[N,K]^T with both operands k-contiguous (see gemm_tiled.hip).
+// dtype: 0 = fp32, 1 = bf16 (fp32 accumulate).  epilogue: 0 forward (+bias, ReLU, optional transposed copy Ct
+// and fp32 copy C32), 1 backward (mask > 0, optional Ct), 2 weight gradient (C is always fp32; bias_out = row
+// sums of B = column sums of dY).
+struct DtfGemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  void* Ct;
+  float* C32;
+  const float* bias;
+  const void* mask;
+  float* bias_out;
+  int M, N, K;
+  int lda, ldb, ldc, ldct, ldc32, ldmask;
+  int relu;
+  int epilogue;
+  int dtype;
+  unsigned a_bytes, b_bytes;
+};
+
+DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_gather_cast_transpose(const float* src, const int* rows, void* dst, void* dstT, int M, int N, int lds_,
+                                         int ldd, int ldt, int dtype, hipStream_t s);
 DTF_EXPORT int dtf_small_gemm(const DtfSmallGemmArgs* a, hipStream_t s);
 DTF_EXPORT int dtf_wgrad_grouped(const DtfWgradArgs* a, hipStream_t s);
 DTF_EXPORT int dtf_head(const DtfHeadArgs* a, hipStream_t s);

@@ -1,0 +1,324 @@
+// Throughput GEMM for the wide layers:  C[M,N] = A[M,K] . B[N,K]^T   (both operands k-contiguous)
+//
+// All three products of a dense layer are brought to this one form by keeping
+// transposed copies where a product needs them (they are written by the
+// producing kernel's epilogue, never by a separate transpose pass over HBM):
+//
+//   forward    Y  = X  . W        A = X [batch,in]      B = W^T [out,in]      (+bias, ReLU)
+//   backward   dX = dY . W^T      A = dY [batch,out]    B = W   [in,out]      (* (act > 0))
+//   gradient   dW = X^T . dY      A = X^T [in,batch]    B = dY^T [out,batch]  (+ db = rowsum(dY^T))
+//
+// Tile: 128x128 per workgroup, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles of 16x16.
+// K-step per LDS stage: 128 bytes per row (64 bf16 / 32 fp32), two stages (double buffer),
+// register-staged: the global loads of stage t+1 are issued before the MFMAs of stage t and
+// written to the other LDS buffer after them, one barrier per stage.
+// LDS rows are 128 B; the 16-byte slot index is XOR-ed with (row & 7), which makes every
+// ds_read_b128 fragment read conflict-free (the 16-lane groups of a b128 read cover 16
+// distinct slots of the 256-byte bank row).
+// bf16: v_mfma_f32_16x16x32_bf16, fp32 accumulate.  fp32: v_mfma_f32_16x16x4_f32 (exact fp32).
+// Workgroup ids are remapped so that the workgroups sharing an XCD (ids equal mod 8) cover a
+// contiguous band of tiles and share operand panels in that XCD's L2.
+#include "dtf_kernels.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+static constexpr unsigned kOOB = 0xFFFFFFF0u;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even; NaN stays NaN
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+enum { EPI_FWD = 0, EPI_BWD = 1, EPI_WGRAD = 2 };
+
+template <typename T> struct Elem;
+template <> struct Elem<unsigned short> { static constexpr int PER16 = 8; };   // bf16 elements per 16 bytes
+template <> struct Elem<unsigned int> { static constexpr int PER16 = 4; };      // fp32 carried as its bit pattern
+
+template <typename T>
+__device__ __forceinline__ void mma_slot(const u32x4& a, const u32x4& b, f32x4& c);
+template <>
+__device__ __forceinline__ void mma_slot<unsigned short>(const u32x4& a, const u32x4& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_slot<unsigned int>(const u32x4& a, const u32x4& b, f32x4& c) {
+  // lane group g holds k = 4g..4g+3 of this 16-deep slot; MFMA j consumes element j of every group
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(DtfGemmArgs p) {
+  constexpr int PER16 = Elem<T>::PER16;
+  constexpr int BKE = 8 * PER16;             // elements per 128-byte LDS row
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * 128];   // [stage][A|B][row*128 + byte]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
+  const int wg = dtf_xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  // consecutive (remapped) ids walk down a column band of 8 row-tiles: A panels and one B panel stay in L2
+  const int band = 8;
+  const int per_band = band * tiles_n;
+  const int b_idx = wg / per_band, in_band = wg % per_band;
+  const int rows_in_band = min(band, tiles_m - b_idx * band);
+  const int tm = b_idx * band + in_band % rows_in_band;
+  const int tn = in_band / rows_in_band;
+  const int m0 = tm << 7, n0 = tn << 7;
+
+  const rsrc_t ra = make_rsrc(p.A, p.a_bytes), rb = make_rsrc(p.B, p.b_bytes);
+
+  // staging map: 1024 16-byte chunks per operand tile, 4 per thread; chunk = (row, slot)
+  unsigned a_goff[4], b_goff[4];
+  unsigned l_off[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int id = tid + 256 * c;
+    const int row = id >> 3, slot = id & 7;
+    a_goff[c] = (m0 + row < p.M) ? (unsigned)(m0 + row) * (unsigned)p.lda * (unsigned)sizeof(T) + (unsigned)slot * 16u : kOOB;
+    b_goff[c] = (n0 + row < p.N) ? (unsigned)(n0 + row) * (unsigned)p.ldb * (unsigned)sizeof(T) + (unsigned)slot * 16u : kOOB;
+    l_off[c] = (unsigned)row * 128u + (unsigned)((slot ^ (row & 7)) << 4);
+  }
+  const int nstage = (p.K + BKE - 1) / BKE;
+  u32x4 ra_reg[4], rb_reg[4];
+  auto stage_load = [&](int t) {
+    const int k0 = t * BKE;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int slot = (tid + 256 * c) & 7;
+      const bool kin = k0 + slot * PER16 < p.K;           // K is a multiple of PER16 (checked by the launcher)
+      const unsigned kb = (unsigned)k0 * (unsigned)sizeof(T);
+      ra_reg[c] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)((kin && a_goff[c] != kOOB) ? a_goff[c] + kb : kOOB), 0, 0);
+      rb_reg[c] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)((kin && b_goff[c] != kOOB) ? b_goff[c] + kb : kOOB), 0, 0);
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<u32x4*>(&lds[buf][0][l_off[c]]) = ra_reg[c];
+      *reinterpret_cast<u32x4*>(&lds[buf][1][l_off[c]]) = rb_reg[c];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bias_grad[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row r = wave base + 16 i + fr, slot s = 4 ks + g  ->  r*128 + ((s ^ (r & 7)) << 4)
+  unsigned a_roff[4], b_roff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_roff[i] = (unsigned)(wm * 64 + i * 16 + fr) * 128u;
+    b_roff[i] = (unsigned)(wn * 64 + i * 16 + fr) * 128u;
+  }
+  const int sw = fr & 7;     // (row & 7) == (fr & 7): the row bases are multiples of 16
+
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+  for (int t = 0; t < nstage; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nstage) stage_load(t + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned so = (unsigned)(((4 * ks + g) ^ sw) << 4);
+      u32x4 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *reinterpret_cast<const u32x4*>(&lds[cur][0][a_roff[i] + so]);
+        bf[i] = *reinterpret_cast<const u32x4*>(&lds[cur][1][b_roff[i] + so]);
+      }
+      if (EPI == EPI_WGRAD) {
+        // db[n] = sum_k dY^T[n][k]: each lane adds the 16 bytes it holds of its B rows
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias_grad[i] += bf2f((unsigned short)(bf[i][e] & 0xffff)) + bf2f((unsigned short)(bf[i][e] >> 16));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias_grad[i] += __uint_as_float(bf[i][e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma_slot<T>(af[i], bf[j], acc[i][j]);
+    }
+    if (t + 1 < nstage) stage_write(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue: acc[i][j][r] = C[m0 + wm*64 + 16i + 4g + r][n0 + wn*64 + 16j + fr]
+  T* __restrict__ C = static_cast<T*>(p.C);
+  T* __restrict__ Ct = static_cast<T*>(p.Ct);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + wn * 64 + 16 * j + fr;
+    const bool col_ok = col < p.N;
+    const float bias = (EPI == EPI_FWD && p.bias && col_ok) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row0 = m0 + wm * 64 + 16 * i + 4 * g;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] + bias;
+        if (EPI == EPI_FWD && p.relu) v[r] = fmaxf(v[r], 0.f);
+        if (EPI == EPI_BWD && col_ok && row0 + r < p.M) {
+          const T m = static_cast<const T*>(p.mask)[(size_t)(row0 + r) * p.ldmask + col];
+          const float mf = sizeof(T) == 2 ? bf2f((unsigned short)m) : __uint_as_float((unsigned)m);
+          v[r] = mf > 0.f ? v[r] : 0.f;
+        }
+      }
+      if (!col_ok) continue;
+      if (EPI == EPI_WGRAD) {
+        float* __restrict__ Cf = static_cast<float*>(p.C);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (row0 + r < p.M) Cf[(size_t)(row0 + r) * p.ldc + col] = v[r];
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (row0 + r < p.M) {
+          if (sizeof(T) == 2) C[(size_t)(row0 + r) * p.ldc + col] = (T)f2bf(v[r]);
+          else C[(size_t)(row0 + r) * p.ldc + col] = (T)__float_as_uint(v[r]);
+          if (p.C32) p.C32[(size_t)(row0 + r) * p.ldc32 + col] = v[r];
+        }
+      }
+      if (Ct) {
+        // transposed copy: the 4 rows a lane holds are contiguous in Ct's row `col`
+        if (row0 + 3 < p.M && (p.ldct & 3) == 0) {
+          if (sizeof(T) == 2) {
+            uint2 pk;
+            pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(&Ct[(size_t)col * p.ldct + row0]) = pk;
+          } else {
+            *reinterpret_cast<float4*>(&Ct[(size_t)col * p.ldct + row0]) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (row0 + r < p.M) {
+              if (sizeof(T) == 2) Ct[(size_t)col * p.ldct + row0 + r] = (T)f2bf(v[r]);
+              else Ct[(size_t)col * p.ldct + row0 + r] = (T)__float_as_uint(v[r]);
+            }
+        }
+      }
+    }
+  }
+  if (EPI == EPI_WGRAD && p.bias_out && tm == 0 && wm == 0) {
+    // lanes fr of the 4 lane groups hold disjoint k ranges of B row (wn*64 + 16i + fr)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = bias_grad[i];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const int col = n0 + wn * 64 + 16 * i + fr;
+      if (g == 0 && col < p.N) p.bias_out[col] = s;
+    }
+  }
+}
+
+template <typename T>
+static int launch_tiled(const DtfGemmArgs& a, hipStream_t s) {
+  const int tiles = dtf_cdiv(a.M, 128) * dtf_cdiv(a.N, 128);
+  dim3 grid(tiles), block(256);
+  switch (a.epilogue) {
+    case EPI_FWD: hipLaunchKernelGGL((gemm_tiled_kernel<T, EPI_FWD>), grid, block, 0, s, a); break;
+    case EPI_BWD: hipLaunchKernelGGL((gemm_tiled_kernel<T, EPI_BWD>), grid, block, 0, s, a); break;
+    case EPI_WGRAD: hipLaunchKernelGGL((gemm_tiled_kernel<T, EPI_WGRAD>), grid, block, 0, s, a); break;
+    default: return DTF_ERR_ARG;
+  }
+  return dtf_check_launch();
+}
+
+DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s) {
+  if (!a || !a->A || !a->B || !a->C) return DTF_ERR_ARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return DTF_ERR_SHAPE;
+  const int per16 = a->dtype == 1 ? 8 : 4;
+  if (a->dtype != 0 && a->dtype != 1) return DTF_ERR_ARG;
+  // 16-byte staging loads: K and both leading dimensions in whole 16-byte chunks, aligned bases
+  if (a->K % per16 || a->lda % per16 || a->ldb % per16) return DTF_ERR_ALIGN;
+  if (!dtf_aligned16(a->A) || !dtf_aligned16(a->B)) return DTF_ERR_ALIGN;
+  if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N) return DTF_ERR_SHAPE;
+  const uint64_t es = a->dtype == 1 ? 2 : 4;
+  if (a->a_bytes == 0 || a->b_bytes == 0 || a->a_bytes >= kOOB || a->b_bytes >= kOOB) return DTF_ERR_SHAPE;
+  if (((uint64_t)(a->M - 1) * a->lda + a->K) * es > a->a_bytes) return DTF_ERR_SHAPE;
+  if (((uint64_t)(a->N - 1) * a->ldb + a->K) * es > a->b_bytes) return DTF_ERR_SHAPE;
+  if (a->epilogue == EPI_BWD && (!a->mask || a->ldmask < a->N)) return DTF_ERR_ARG;
+  if (a->Ct && a->ldct < a->M) return DTF_ERR_SHAPE;
+  if (a->C32 && a->ldc32 < a->N) return DTF_ERR_SHAPE;
+  if (a->epilogue == EPI_WGRAD && (a->Ct || a->C32)) return DTF_ERR_ARG;
+  return a->dtype == 1 ? launch_tiled<unsigned short>(*a, s) : launch_tiled<unsigned int>(*a, s);
+}
+
+// --------------------------------------------------------------------------------------
+// helpers of the wide pipeline (pure streaming kernels)
+// --------------------------------------------------------------------------------------
+// dst[i] = src[rows[i]] converted to T, plus the transposed copy dstT[c][i]  (batch gather for layer 1)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_cast_transpose_kernel(const float* __restrict__ src, const int* __restrict__ rows,
+                                                                    T* __restrict__ dst, T* __restrict__ dstT, int M, int N,
+                                                                    int lds_, int ldd, int ldt) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int r = r0 + rr, c = c0 + tx;
+    float v = 0.f;
+    if (r < M && c < N) {
+      const int sr = rows ? rows[r] : r;
+      v = src[(size_t)sr * lds_ + c];
+      if (dst) {
+        if (sizeof(T) == 2) dst[(size_t)r * ldd + c] = (T)f2bf(v);
+        else dst[(size_t)r * ldd + c] = (T)__float_as_uint(v);
+      }
+    }
+    tile[rr][tx] = v;
+  }
+  __syncthreads();
+  if (dstT) {
+    for (int cc = ty; cc < 32; cc += 8) {
+      const int c = c0 + cc, r = r0 + tx;
+      if (c < N && r < M) {
+        const float v = tile[tx][cc];
+        if (sizeof(T) == 2) dstT[(size_t)c * ldt + r] = (T)f2bf(v);
+        else dstT[(size_t)c * ldt + r] = (T)__float_as_uint(v);
+      }
+    }
+  }
+}
+
+DTF_EXPORT int dtf_gather_cast_transpose(const float* src, const int* rows, void* dst, void* dstT, int M, int N, int lds_,
+                                         int ldd, int ldt, int dtype, hipStream_t s) {
+  if (!src || (!dst && !dstT)) return DTF_ERR_ARG;
+  if (M <= 0 || N <= 0 || lds_ < N || (dst && ldd < N) || (dstT && ldt < M)) return DTF_ERR_SHAPE;
+  if (dtf_cdiv(M, 32) > 65535) return DTF_ERR_SHAPE;
+  dim3 grid(dtf_cdiv(N, 32), dtf_cdiv(M, 32)), block(256);
+  if (dtype == 1)
+    hipLaunchKernelGGL(gather_cast_transpose_kernel<unsigned short>, grid, block, 0, s, src, rows, (unsigned short*)dst,
+                       (unsigned short*)dstT, M, N, lds_, ldd, ldt);
+  else if (dtype == 0)
+    hipLaunchKernelGGL(gather_cast_transpose_kernel<unsigned int>, grid, block, 0, s, src, rows, (unsigned int*)dst,
+                       (unsigned int*)dstT, M, N, lds_, ldd, ldt);
+  else
+    return DTF_ERR_ARG;
+  return dtf_check_launch();
+}

@@ -309,3 +309,95 @@ def truncated_normal_(out, stddev, seed, stream_id=0):
     _lib.check(_lib.kernels().dtf_truncated_normal(_f32c(out, "out").data_ptr(), out.numel(), stddev, int(seed),
                                                    int(stream_id), _lib.stream_handle()), "truncated_normal")
     return out
+
+
+# --------------------------------------------------------------------------- tiled GEMM (wide layers)
+EPI_FWD, EPI_BWD, EPI_WGRAD = 0, 1, 2
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise ValueError(f"tiled GEMM supports float32 and bfloat16, got {t.dtype}")
+
+
+def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t=None, out_f32=None, bias_out=None,
+            m=None):
+    """``out[:m] = epilogue(a[:m] @ b^T)`` with ``a`` [M,K] and ``b`` [N,K], both k-contiguous.
+
+    forward: ``+bias``, ReLU, optional transposed copy ``out_t`` [N,M] and fp32 copy ``out_f32``;
+    backward: zero where ``mask <= 0``, optional ``out_t``;
+    weight gradient: ``out`` is fp32, ``bias_out[n] = sum_k b[n,k]``.
+    """
+    M = m if m is not None else a.shape[0]
+    N, K = b.shape
+    if a.shape[1] != K:
+        raise ValueError(f"gemm_nt: a is [*, {a.shape[1]}], b is [*, {K}]")
+    if a.dtype != b.dtype:
+        raise ValueError("gemm_nt: operand dtypes differ")
+    if not a.is_cuda:
+        c = a[:M].float() @ b.float().t()
+        if epilogue == EPI_FWD:
+            if bias is not None:
+                c = c + bias
+            if relu:
+                c = torch.relu(c)
+        elif epilogue == EPI_BWD:
+            c = torch.where(mask[:M].float() > 0, c, torch.zeros_like(c))
+        else:
+            if bias_out is not None:
+                bias_out.copy_(b.float().sum(1))
+        out[:M].copy_(c.to(out.dtype))
+        if out_t is not None:
+            out_t[:, :M].copy_(c.t().to(out_t.dtype))
+        if out_f32 is not None:
+            out_f32[:M].copy_(c)
+        return out
+    _same_device(a, b, out, bias, mask, out_t, out_f32, bias_out)
+    want_out = torch.float32 if epilogue == EPI_WGRAD else a.dtype
+    if out.dtype != want_out or out.shape[0] < M or out.shape[1] != N:
+        raise ValueError(f"gemm_nt: out must be {want_out} [>={M},{N}], got {out.dtype} {tuple(out.shape)}")
+    for name, t in (("a", a), ("b", b), ("out", out)):
+        if t.stride(-1) != 1:
+            raise ValueError(f"gemm_nt: {name} must be row-major")
+    if out_t is not None and (out_t.dtype != a.dtype or out_t.shape[0] != N or out_t.shape[1] < M):
+        raise ValueError("gemm_nt: out_t must be [N, >=M] of the operand dtype")
+    if out_f32 is not None and (out_f32.dtype != torch.float32 or out_f32.shape[0] < M or out_f32.shape[1] != N):
+        raise ValueError("gemm_nt: out_f32 shape/dtype mismatch")
+    if mask is not None and (mask.dtype != a.dtype or mask.shape[0] < M or mask.shape[1] != N):
+        raise ValueError("gemm_nt: mask must be [>=M, N] of the operand dtype")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
+        raise ValueError("gemm_nt: bias must be float32 [N]")
+    if bias_out is not None and (bias_out.dtype != torch.float32 or bias_out.numel() != N):
+        raise ValueError("gemm_nt: bias_out must be float32 [N]")
+    args = _lib.GemmArgs(A=a.data_ptr(), B=b.data_ptr(), C=out.data_ptr(), Ct=_lib.ptr(out_t), C32=_lib.ptr(out_f32),
+                         bias=_lib.ptr(bias), mask=_lib.ptr(mask), bias_out=_lib.ptr(bias_out), M=M, N=N, K=K,
+                         lda=a.stride(0), ldb=b.stride(0), ldc=out.stride(0), ldct=0 if out_t is None else out_t.stride(0),
+                         ldc32=0 if out_f32 is None else out_f32.stride(0), ldmask=0 if mask is None else mask.stride(0),
+                         relu=int(bool(relu)), epilogue=epilogue, dtype=_dtype_code(a), a_bytes=_lib.span_bytes(a),
+                         b_bytes=_lib.span_bytes(b))
+    _lib.check(_lib.kernels().dtf_gemm_tiled(C.byref(args), _lib.stream_handle()), "gemm_nt")
+    return out
+
+
+def gather_cast_transpose(src, rows, dst=None, dst_t=None, m=None):
+    """``dst[i] = src[rows[i]]`` (cast to dst's dtype) and ``dst_t = dst^T``; the batch gather of the wide pipeline."""
+    M = m if m is not None else (rows.numel() if rows is not None else src.shape[0])
+    N = src.shape[1]
+    ref = dst if dst is not None else dst_t
+    if not src.is_cuda:
+        x = src.index_select(0, rows[:M].long()) if rows is not None else src[:M]
+        if dst is not None:
+            dst[:M].copy_(x.to(dst.dtype))
+        if dst_t is not None:
+            dst_t[:, :M].copy_(x.t().to(dst_t.dtype))
+        return ref
+    if dst is not None and dst_t is not None and dst.dtype != dst_t.dtype:
+        raise ValueError("gather_cast_transpose: dst and dst_t dtypes differ")
+    _lib.check(_lib.kernels().dtf_gather_cast_transpose(
+        _f32c(src, "src").data_ptr(), _lib.ptr(None if rows is None else _i32c(rows, "rows")), _lib.ptr(dst), _lib.ptr(dst_t),
+        M, N, src.stride(0), 0 if dst is None else dst.stride(0), 0 if dst_t is None else dst_t.stride(0), _dtype_code(ref),
+        _lib.stream_handle()), "gather_cast_transpose")
+    return ref

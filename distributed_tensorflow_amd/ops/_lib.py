@@ -64,6 +64,14 @@ class HeadArgs(C.Structure):
                 ("inv_b", C.c_float), ("h_bytes", C.c_uint), ("pad_", C.c_int)]
 
 
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("Ct", C.c_void_p), ("C32", C.c_void_p),
+                ("bias", C.c_void_p), ("mask", C.c_void_p), ("bias_out", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
+                ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ldct", C.c_int), ("ldc32", C.c_int),
+                ("ldmask", C.c_int), ("relu", C.c_int), ("epilogue", C.c_int), ("dtype", C.c_int), ("a_bytes", C.c_uint),
+                ("b_bytes", C.c_uint)]
+
+
 def span_bytes(t) -> int:
     """Bytes addressable from ``t.data_ptr()`` for a row-major 2-D (or 1-D) tensor view."""
     if t.dim() == 1:
@@ -90,8 +98,11 @@ def _declare_kernels(lib):
     lib.dtf_adam_apply.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, i32, vp]
     lib.dtf_truncated_normal.argtypes = [vp, i64, f32, u64, u64, vp]
     lib.dtf_accumulate.argtypes = [vp, vp, i64, f32, f32, vp]
+    lib.dtf_gemm_tiled.argtypes = [C.POINTER(GemmArgs), vp]
+    lib.dtf_gather_cast_transpose.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     for name in ("dtf_small_gemm", "dtf_wgrad_grouped", "dtf_head", "dtf_step_tail", "dtf_sgd_apply", "dtf_adam_apply",
-                 "dtf_truncated_normal", "dtf_accumulate", "dtf_kernels_abi_version"):
+                 "dtf_truncated_normal", "dtf_accumulate", "dtf_kernels_abi_version", "dtf_gemm_tiled",
+                 "dtf_gather_cast_transpose"):
         getattr(lib, name).restype = i32
 
 

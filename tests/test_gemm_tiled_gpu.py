@@ -1,0 +1,89 @@
+"""Tiled MFMA GEMM (fp32 exact and bf16) vs a plain PyTorch fp32 statement of the same product."""
+import pytest
+import torch
+
+from distributed_tensorflow_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _tol(dtype, K):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2 * (K ** 0.5) * 0.02)
+
+
+def _check(got, want, rtol, atol):
+    err = (got.float().cpu() - want).abs().max().item()
+    assert err <= atol + rtol * want.abs().max().item(), f"max err {err} vs magnitude {want.abs().max().item()}"
+
+
+def test_layout_identity_asymmetric():
+    for dtype in (torch.float32, torch.bfloat16):
+        n = 256
+        eye = torch.eye(n)
+        b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) - 125      # exact in bf16
+        out = torch.zeros(n, n, dtype=dtype, device=DEV)
+        ops.gemm_nt(eye.to(DEV, dtype), b.to(DEV, dtype), out)            # out = I @ b^T
+        assert torch.equal(out.float().cpu(), b.t())
+        ops.gemm_nt(b.to(DEV, dtype), eye.to(DEV, dtype), out)            # out = b @ I
+        assert torch.equal(out.float().cpu(), b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 4096, 784), (1000, 520, 4096), (136, 72, 200), (8, 8, 8)])
+def test_forward_epilogue(dtype, M, N, K):
+    a, b, bias = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.1), _rand(N, seed=3)
+    ad, bd = a.to(DEV, dtype), b.to(DEV, dtype)
+    want = torch.relu(ad.float().cpu() @ bd.float().cpu().t() + bias)
+    out = torch.zeros(M, N, dtype=dtype, device=DEV)
+    Mp = (M + 7) // 8 * 8
+    out_t = torch.zeros(N, Mp, dtype=dtype, device=DEV)
+    out32 = torch.zeros(M, N, device=DEV)
+    ops.gemm_nt(ad, bd, out, ops.EPI_FWD, bias=bias.to(DEV), relu=True, out_t=out_t, out_f32=out32)
+    rtol, atol = _tol(dtype, K)
+    _check(out32, want, 2e-5 if dtype == torch.float32 else 1e-3, 1e-4)
+    _check(out, want, rtol, atol)
+    assert torch.equal(out_t[:, :M].float().cpu(), out.float().cpu().t())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_backward_and_wgrad_epilogues(dtype):
+    M, IN, OUT = 264, 328, 200
+    dy, w, act = _rand(M, OUT, seed=1), _rand(IN, OUT, seed=2, scale=0.1), _rand(M, IN, seed=3)
+    dyd, wd, actd = dy.to(DEV, dtype), w.to(DEV, dtype), act.to(DEV, dtype)
+    want = torch.where(actd.float().cpu() > 0, dyd.float().cpu() @ wd.float().cpu().t(), torch.zeros(M, IN))
+    dx = torch.zeros(M, IN, dtype=dtype, device=DEV)
+    dx_t = torch.zeros(IN, M, dtype=dtype, device=DEV)
+    ops.gemm_nt(dyd, wd, dx, ops.EPI_BWD, mask=actd, out_t=dx_t)
+    rtol, atol = _tol(dtype, OUT)
+    _check(dx, want, rtol, atol)
+    assert torch.equal(dx_t.float().cpu(), dx.float().cpu().t())
+    # dW[in,out] = X^T dY from the transposed copies; db = column sums of dY
+    x_t, dy_t = _rand(IN, M, seed=4).to(DEV, dtype), dyd.t().contiguous()
+    dw = torch.zeros(IN, OUT, device=DEV)
+    db = torch.zeros(OUT, device=DEV)
+    ops.gemm_nt(x_t, dy_t, dw, ops.EPI_WGRAD, bias_out=db)
+    _check(dw, x_t.float().cpu() @ dyd.float().cpu(), 2e-5 if dtype == torch.float32 else 2e-3, 1e-4)
+    _check(db, dyd.float().cpu().sum(0), 2e-5 if dtype == torch.float32 else 2e-3, 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_cast_transpose(dtype):
+    src = _rand(500, 784, seed=1)
+    rows = torch.randperm(500, generator=torch.Generator().manual_seed(2))[:136].to(torch.int32)
+    dst = torch.zeros(136, 784, dtype=dtype, device=DEV)
+    dst_t = torch.zeros(784, 136, dtype=dtype, device=DEV)
+    ops.gather_cast_transpose(src.to(DEV), rows.to(DEV), dst, dst_t)
+    want = src[rows.long()].to(dtype)
+    assert torch.equal(dst.cpu(), want) and torch.equal(dst_t.cpu(), want.t())
+
+
+def test_rejects_unaligned_k():
+    a = torch.zeros(16, 10, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(a, a, torch.zeros(16, 16, dtype=torch.bfloat16, device=DEV))
