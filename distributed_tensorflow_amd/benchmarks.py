@@ -11,6 +11,7 @@ from . import ops
 from .data import mnist
 from .data.device_dataset import DeviceDataset
 from .models.mlp import MLPProgram, build_mlp_state
+from .models.wide_mlp import WideMLPProgram
 from .parallel import comm
 from .parallel.sync_replicas import SyncReplicasEngine
 
@@ -60,9 +61,15 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer=optimizer, lr=lr)
     state.initialize(seed=1234)                      # same seed everywhere == chief init + broadcast
     data = DeviceDataset(ds.train, device, shuffle_seed=1000 + rank)
-    fused = world == 1 and optimizer == "sgd"
-    prog = MLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, fused_update=fused,
-                      post_update_accuracy=not args.no_post_update_accuracy, gs_inc=1)
+    fused = world == 1 and optimizer == "sgd" and not wide
+    dtype_name = args.dtype or "fp32"
+    if wide:
+        cdtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+        prog = WideMLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, dtype=cdtype, gs_inc=1)
+        args.no_post_update_accuracy = True
+    else:
+        prog = MLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, fused_update=fused,
+                          post_update_accuracy=not args.no_post_update_accuracy, gs_inc=1)
     engine = SyncReplicasEngine(prog, state, collective=args.collective)
     graph_steps = args.graph_steps or 64
     _sync_all(device, world)
@@ -80,7 +87,7 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     return {
         "metric": METRIC, "value": value, "unit": "examples/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "fp32", "data": "synthetic MNIST-shape (resident in HBM), random-init weights",
+        "vs_baseline": None, "dtype": dtype_name if wide else "fp32", "data": "synthetic MNIST-shape (resident in HBM), random-init weights",
         "config": {"model": ("wide_mlp 784-7x4096-10" if wide else f"reference MLP 784-{hidden_units}-10"),
                    "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
                    "parallelism": f"dp{world} sync_replicas R={world}, ps state sharded over {world} GPU(s)",

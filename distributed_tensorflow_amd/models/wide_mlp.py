@@ -1,0 +1,140 @@
+"""Wide MLP (4096-wide hidden layers, ~100 M parameters): the bandwidth/MFMA-bound configuration.
+
+Same network family, loss and bookkeeping as the reference model (``mlp.py``), but the hidden
+layers run on the tiled MFMA GEMM (``csrc/kernels/gemm_tiled.hip``) in bf16 with fp32
+accumulation and fp32 master weights, or in exact fp32.  Every product is of the form
+``A[M,K] . B[N,K]^T``; the transposed operand copies that the backward products need
+(``H^T``, ``dZ^T``, ``W^T``) are written by the epilogue of the kernel that produces the tensor.
+
+Per step:  gather+cast batch -> L x forward GEMM (+bias, ReLU) -> head (loss, accuracy, dz)
+-> (L-1) x backward GEMM (ReLU mask) -> L x weight-gradient GEMM (+bias gradient) -> small
+kernel for the 10-class layer -> optimizer / collectives -> refresh of the compute copies.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from .. import ops
+from ..data.device_dataset import DeviceDataset
+from ..parallel.sharded_state import ShardedState
+from .mlp import MLPProgram
+
+
+class WideMLPProgram(MLPProgram):
+    def __init__(self, state: ShardedState, dataset: DeviceDataset, batch: int, hidden: Sequence[int], classes: int = 10,
+                 loss_mode: int = ops.LOSS_REFERENCE, dtype: torch.dtype = torch.bfloat16, gs_inc: int = 1,
+                 log_capacity: int = 2048, use_graphs: Optional[bool] = None):
+        if batch % 8 or any(h % 8 for h in hidden):
+            raise ValueError("wide MLP: batch and hidden sizes must be multiples of 8 (16-byte GEMM staging)")
+        self.cdtype = dtype
+        super().__init__(state, dataset, batch, hidden, classes, loss_mode, fused_update=False,
+                         post_update_accuracy=False, gs_inc=gs_inc, log_capacity=log_capacity, use_graphs=use_graphs)
+        dev, B, T = self.device, batch, dtype
+        d_in = dataset.images.shape[1]
+        dims = [d_in] + list(hidden)
+        self.dims = dims
+        z = lambda *s: torch.zeros(*s, dtype=T, device=dev)
+        self.xb, self.xb_t = z(B, d_in), z(d_in, B)
+        self.h = [z(B, h) for h in hidden]                 # activations in the compute dtype
+        self.h_t = [z(h, B) for h in hidden[:-1]]          # transposed copies feed the weight gradients
+        self.hl32 = self.hact[-1]                          # fp32 copy of the last hidden layer for the head kernel
+        self.hl_t = z(hidden[-1], B)
+        self.dzc = [z(B, h) for h in hidden]
+        self.dzc_t = [z(h, B) for h in hidden]
+        # compute copies of the weights: W [in,out] for the backward product, W^T [out,in] for the forward one
+        self.w = [None if T == torch.float32 else z(dims[i], dims[i + 1]) for i in range(len(hidden))]
+        self.w_t = [z(dims[i + 1], dims[i]) for i in range(len(hidden))]
+        self.refresh_compute_copies()
+
+    def _build_args(self, q: int):
+        st = self.state
+        head = ops.build_head_args(self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B,
+                                   self.loss_mode, rows=self.ridx[q], dz2=self.dz2, dz1=self.dz[-1],
+                                   loss_part=self.loss_part, correct_part=self.correct_part, post_part=self.post_part)
+        items = [ops.WgradItem(self.hact[-1], self.dz2, self.B, n=self.C, dw=st.grad("sm_w"), db=st.grad("sm_b"),
+                               w=st.var("sm_w"), b=st.var("sm_b"))]
+        wgrad = ops.build_wgrad_args(items, lr=None, tail=self._tail(q))
+        return {"head": head, "wgrad": wgrad, "items": items}
+
+    def refresh_compute_copies(self) -> None:
+        """After an update of the fp32 master weights: rewrite W (compute dtype) and W^T."""
+        st = self.state
+        for l, name in enumerate(self.names):
+            master = st.var(f"{name}_w")
+            ops.gather_cast_transpose(master, None, self.w[l], self.w_t[l])
+
+    def _weight(self, l: int) -> torch.Tensor:
+        return self.w[l] if self.w[l] is not None else self.state.var(f"{self.names[l]}_w")
+
+    def enqueue_step(self) -> None:
+        q = self.steps_enqueued & 1
+        st, B, L = self.state, self.B, len(self.names)
+        rows = self.ridx[q]
+        ops.gather_cast_transpose(self.data.images, rows, self.xb, self.xb_t, m=B)
+        x = self.xb
+        for l, name in enumerate(self.names):
+            last = l == L - 1
+            ops.gemm_nt(x, self.w_t[l], self.h[l], ops.EPI_FWD, bias=st.var(f"{name}_b"), relu=True,
+                        out_t=self.hl_t if last else self.h_t[l], out_f32=self.hl32 if last else None, m=B)
+            x = self.h[l]
+        if self.is_cuda:
+            ops.head(self.hl32, st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, B, args=self._args[q]["head"])
+        else:
+            ops.head(self.hl32, st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, B, self.loss_mode, rows=rows,
+                     dz2=self.dz2, dz1=self.dz[-1], loss_part=self.loss_part, correct_part=self.correct_part,
+                     post_part=self.post_part)
+        # dz of the last hidden layer: fp32 from the head -> compute dtype + transposed copy
+        ops.gather_cast_transpose(self.dz[-1], None, self.dzc[-1], self.dzc_t[-1], m=B)
+        for l in range(L - 1, 0, -1):
+            ops.gemm_nt(self.dzc[l], self._weight(l), self.dzc[l - 1], ops.EPI_BWD, mask=self.h[l - 1],
+                        out_t=self.dzc_t[l - 1], m=B)
+        for l, name in enumerate(self.names):
+            a_t = self.xb_t if l == 0 else self.h_t[l - 1]
+            ops.gemm_nt(a_t, self.dzc_t[l], st.grad(f"{name}_w"), ops.EPI_WGRAD, bias_out=st.grad(f"{name}_b"))
+        if self.is_cuda:
+            ops.wgrad_grouped(self._args[q]["items"], args=self._args[q]["wgrad"])
+        else:
+            st_ = self.state
+            ops.wgrad_grouped([ops.WgradItem(self.hact[-1], self.dz2, self.B, n=self.C, dw=st_.grad("sm_w"),
+                                             db=st_.grad("sm_b"), w=st_.var("sm_w"), b=st_.var("sm_b"))], lr=None)
+            self._tail_cpu(q, init_only=False)
+        if self.after_compute is not None:
+            self.after_compute()
+        self.refresh_compute_copies()
+        self.steps_enqueued += 1
+
+    def _count_correct(self, images, labels, rows=None, n=None, chunk: int = 8192) -> int:
+        n = n if n is not None else images.shape[0]
+        st, T = self.state, self.cdtype
+        total = 0
+        for lo in range(0, n, chunk):
+            m = min(chunk, n - lo)
+            mp = (m + 7) // 8 * 8
+            buf = self._eval_buf.get(mp)
+            if buf is None:
+                nb = (m + 15) // 16
+                buf = {"x": torch.zeros((mp, images.shape[1]), dtype=T, device=self.device),
+                       "h": [torch.zeros((mp, h), dtype=T, device=self.device) for h in self.hidden],
+                       "h32": torch.zeros((mp, self.hidden[-1]), dtype=torch.float32, device=self.device),
+                       "lp": torch.zeros(nb, dtype=torch.float32, device=self.device),
+                       "cp": torch.zeros(nb, dtype=torch.int32, device=self.device),
+                       "pp": torch.zeros(nb, dtype=torch.int32, device=self.device)}
+                self._eval_buf = {mp: buf}
+            if rows is not None:
+                ops.gather_cast_transpose(images, rows[lo:lo + m].contiguous(), buf["x"], None, m=m)
+                lab, lrows = labels, rows[lo:lo + m].contiguous()
+            else:
+                ops.gather_cast_transpose(images[lo:lo + m], None, buf["x"], None, m=m)
+                lab, lrows = labels[lo:lo + m], None
+            x = buf["x"]
+            for l, name in enumerate(self.names):
+                last = l == len(self.names) - 1
+                ops.gemm_nt(x, self.w_t[l], buf["h"][l], ops.EPI_FWD, bias=st.var(f"{name}_b"), relu=True,
+                            out_f32=buf["h32"] if last else None, m=m)
+                x = buf["h"][l]
+            ops.head(buf["h32"], st.var("sm_w"), st.var("sm_b"), lab, m, 0, self.loss_mode, rows=lrows, loss_part=buf["lp"],
+                     correct_part=buf["cp"], post_part=buf["pp"])
+            total += int(buf["pp"].sum().item())
+        return total
