@@ -55,12 +55,12 @@ def _open_maybe_gz(path: str):
 
 def read_idx(path: str) -> np.ndarray:
     """Decode one idx file (optionally gzip-compressed) into a uint8 array."""
-    try:
-        from ..utils import native
-        if native.available():
-            return native.read_idx(path)
-    except ImportError:
-        pass
+    from ..utils import native
+    if native.available():
+        real = path if os.path.exists(path) else (path[:-3] if path.endswith(".gz") else path + ".gz")
+        if not os.path.exists(real):
+            raise FileNotFoundError(f"MNIST file not found: {path} (there is no download fallback; pass --synthetic_data)")
+        return native.read_idx(real)
     with _open_maybe_gz(path) as f:
         data = f.read()
     zero, dtype_code, ndim = struct.unpack(">HBB", data[:4])
