@@ -99,6 +99,81 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     }
 
 
+def bench_resnet50_sync(args, rank, world, device):
+    from .models.resnet import TorchModuleProgram, resnet50
+    batch = args.batch_size or 128
+    optimizer = args.optimizer or "adam"
+    dtype_name = args.dtype or "bf16"
+    torch.manual_seed(1234)                                   # identical initial weights on every rank
+    model = resnet50()
+    g = torch.Generator().manual_seed(100 + rank)
+    n = 2 * batch
+    images = torch.rand(n, 3, 224, 224, generator=g)
+    labels = torch.randint(0, 1000, (n,), generator=g)
+    autocast = torch.bfloat16 if dtype_name == "bf16" and device.type == "cuda" else None
+    prog = TorchModuleProgram(model, device, images, labels, batch, world_size=world, rank=rank, optimizer=optimizer,
+                              lr=1e-3 if optimizer == "adam" else 0.1, autocast=autocast)
+    engine = SyncReplicasEngine(prog, prog.state, collective="reduce_scatter" if world > 1 else "auto")
+    _sync_all(device, world)
+    engine.run(args.warmup) if args.warmup > 0 else None
+    _sync_all(device, world)
+    t0 = time.perf_counter()
+    engine.run(args.steps)
+    _sync_all(device, world)
+    dt = _max_over_ranks(time.perf_counter() - t0, device, world)
+    last = prog.read_log(prog.steps_enqueued - 1, 1)[0]
+    return {
+        "metric": METRIC, "value": batch * args.steps * world / dt, "unit": "examples/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype_name if autocast is not None else "fp32",
+        "data": "synthetic ImageNet-shape (resident in HBM), random-init weights",
+        "config": {"model": "ResNet-50", "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
+                   "parallelism": f"dp{world} sync_replicas, optimizer state sharded over {world} GPU(s)",
+                   "optimizer": optimizer, "mode": "sync", "collective": engine.collective if world > 1 else "none",
+                   "params": prog.state.layout.used, "convolutions": "MIOpen (library)"},
+        "final_loss": last.loss,
+    }
+
+
+def bench_mlp_async(args, rank, world, device):
+    from .parallel.async_ps import AsyncParameterServerEngine
+    batch = args.batch_size or 100
+    hidden = [args.hidden_units or 100]
+    ds = mnist.synthetic_data_sets(train_size=55000, validation_size=100, test_size=100, seed=rank)
+    state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer="sgd", lr=0.01)
+    state.initialize(seed=1234)
+    data = DeviceDataset(ds.train, device, shuffle_seed=1000 + rank)
+    if world == 1:
+        prog = MLPProgram(state, data, batch, hidden, fused_update=True, post_update_accuracy=not args.no_post_update_accuracy)
+        engine = SyncReplicasEngine(prog, state)
+        finish = lambda: None
+    else:
+        prog = MLPProgram(state, data, batch, hidden, fused_update=False, gs_inc=0,
+                          post_update_accuracy=not args.no_post_update_accuracy)
+        engine = AsyncParameterServerEngine(prog, state, num_shards=1, staleness=4)
+        finish = engine.finish
+    _sync_all(device, world)
+    engine.run(args.warmup, 64)
+    _sync_all(device, world)
+    t0 = time.perf_counter()
+    engine.run(args.steps, 64)
+    if world > 1:
+        engine.sync_params()
+    _sync_all(device, world)
+    dt = _max_over_ranks(time.perf_counter() - t0, device, world)
+    finish()
+    return {
+        "metric": METRIC, "value": batch * args.steps * world / dt, "unit": "examples/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "fp32",
+        "data": "synthetic MNIST-shape (resident in HBM), random-init weights",
+        "config": {"model": "reference MLP 784-100-10", "global_batch": batch * world, "per_worker_batch": batch,
+                   "seq_len": None, "parallelism": f"dp{world} async push/pull, 1 logical ps shard on rank 0, staleness 4",
+                   "optimizer": "sgd", "mode": "async", "params": state.layout.used},
+        "global_step": state.global_step() if rank == 0 else None,
+    }
+
+
 def run_benchmark(args):
     rank, world, device = _setup_distributed(args)
     if world != args.gpus:
@@ -107,6 +182,10 @@ def run_benchmark(args):
         res = bench_mlp_sync(args, rank, world, device, wide=False)
     elif args.config == "wide_mlp_sync":
         res = bench_mlp_sync(args, rank, world, device, wide=True)
+    elif args.config == "resnet50_sync":
+        res = bench_resnet50_sync(args, rank, world, device)
+    elif args.config == "mlp_async":
+        res = bench_mlp_async(args, rank, world, device)
     else:
         raise SystemExit(f"config {args.config} is not wired into bench.py yet")
     if world > 1:

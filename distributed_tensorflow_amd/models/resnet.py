@@ -1,0 +1,156 @@
+"""ResNet-50 on the sharded parameter-server state (BASELINE configuration 5).
+
+The convolutions are library calls (MIOpen through PyTorch): the reference has no convolutional
+model, and the hand-written hot path of this framework is the dense path.  What this model
+exercises is the parameter-server side at a realistic size (25.6 M parameters, 161 tensors):
+all trainable tensors are views into ONE flat fp32 buffer, autograd writes gradients into the
+matching flat gradient buffer, and a step is
+
+    forward/backward -> reduce-scatter(flat grads) -> fused Adam/SGD on the owned slice -> all-gather
+
+with optimizer state (Adam m, v) existing only for the slice a rank owns.
+"""
+from __future__ import annotations
+
+import struct
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..parallel.sharded_state import ShardedState, VariableSpec
+from .mlp import StepRecord
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        out = F.relu(self.bn2(self.conv2(out)), inplace=True)
+        out = self.bn3(self.conv3(out))
+        return F.relu(out + idt, inplace=True)
+
+
+class ResNet(nn.Module):
+    def __init__(self, layers=(3, 4, 6, 3), num_classes=1000, width=64):
+        super().__init__()
+        self.inplanes = width
+        self.conv1 = nn.Conv2d(3, width, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.layer1 = self._make(width, layers[0], 1)
+        self.layer2 = self._make(width * 2, layers[1], 2)
+        self.layer3 = self._make(width * 4, layers[2], 2)
+        self.layer4 = self._make(width * 8, layers[3], 2)
+        self.fc = nn.Linear(width * 8 * 4, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                 nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        layers += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        x = F.max_pool2d(x, 3, stride=2, padding=1)
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+        return self.fc(x)
+
+
+def resnet50(num_classes=1000, width=64, layers=(3, 4, 6, 3)) -> ResNet:
+    return ResNet(layers, num_classes, width)
+
+
+class TorchModuleProgram:
+    """Step program around a PyTorch module whose parameters live in a ``ShardedState``.
+
+    Has the interface the engines expect from ``MLPProgram`` (``run``, ``after_compute``,
+    ``gs_inc``, ``fused``, ``read_log``) so that ``SyncReplicasEngine`` drives it unchanged.
+    """
+
+    def __init__(self, module: nn.Module, device, images: torch.Tensor, labels: torch.Tensor, batch: int,
+                 world_size: int = 1, rank: int = 0, optimizer: str = "adam", lr: float = 1e-3, gs_inc: int = 1,
+                 autocast: Optional[torch.dtype] = None, channels_last: bool = True, log_capacity: int = 1024):
+        self.device = torch.device(device)
+        self.module = module.to(self.device)
+        if channels_last and images.dim() == 4:
+            self.module = self.module.to(memory_format=torch.channels_last)
+        named = [(n.replace(".", "/"), p) for n, p in self.module.named_parameters()]
+        specs = [VariableSpec(n, tuple(p.shape)) for n, p in named]
+        self.state = ShardedState(specs, self.device, world_size, rank, optimizer, lr)
+        # move every parameter (and its gradient) into the flat buffers
+        for n, p in named:
+            flat = self.state.var(n)
+            flat.copy_(p.detach().reshape(flat.shape))
+            p.data = flat
+            p.grad = self.state.grad(n)
+        self.state.initialized = True
+        self.images, self.labels = images.to(self.device), labels.to(self.device)
+        if channels_last and self.images.dim() == 4:
+            self.images = self.images.contiguous(memory_format=torch.channels_last)
+        self.B = batch
+        self.n = self.images.shape[0]
+        self.autocast = autocast
+        self.gs_inc = gs_inc
+        self.fused = False
+        self.post = False
+        self.use_graphs = False
+        self._graphs = {}
+        self.after_compute = None
+        self.steps_enqueued = 0
+        self.log_cap = log_capacity
+        self.log = torch.zeros((log_capacity, 2), dtype=torch.float32, device=self.device)   # loss, correct
+        self.gs_log = torch.zeros(log_capacity, dtype=torch.int32, device=self.device)
+
+    def enqueue_step(self) -> None:
+        s = self.steps_enqueued
+        lo = (s * self.B) % max(1, self.n - self.B + 1)
+        x, y = self.images[lo:lo + self.B], self.labels[lo:lo + self.B]
+        self.state.grads.zero_()
+        with torch.autocast(self.device.type, dtype=self.autocast, enabled=self.autocast is not None):
+            logits = self.module(x)
+        loss = F.cross_entropy(logits.float(), y)
+        loss.backward()
+        slot = s % self.log_cap
+        self.log[slot, 0] = loss.detach()
+        self.log[slot, 1] = (logits.argmax(1) == y).sum().float()
+        self.gs_log[slot] = self.state.state[0]
+        if self.after_compute is not None:
+            self.after_compute()
+        self.state.state[0:1].add_(self.gs_inc)
+        self.state.state[1:2].add_(1)
+        self.steps_enqueued += 1
+
+    def run(self, n_steps: int, graph_steps: int = 0) -> None:
+        self.module.train()
+        for _ in range(n_steps):
+            self.enqueue_step()
+
+    def read_log(self, first_local_step: int, count: int) -> List[StepRecord]:
+        log, gs = self.log.cpu(), self.gs_log.cpu()
+        out = []
+        for s in range(first_local_step, first_local_step + count):
+            i = s % self.log_cap
+            out.append(StepRecord(local_step=s + 1, global_step=int(gs[i]), loss=float(log[i, 0]),
+                                  train_correct=int(log[i, 1]), batch=self.B))
+        return out
