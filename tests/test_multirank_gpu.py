@@ -1,0 +1,83 @@
+"""Engines with several ranks sharing the one GPU of the test box (gloo carries the tensors, so this
+checks the GPU-side logic of the engines — streams, service threads, captured steps — not RCCL)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from dist_utils import free_port, run_ranks
+from test_cli import COMMON, _finish, _launch, _steps
+
+pytestmark = pytest.mark.gpu
+
+
+def _sync_gpu(rank, world, port, collective):
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=100, test_size=300, seed=rank)
+    st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, lr=0.5)
+    st.initialize(seed=3)
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=rank), 100, [100], fused_update=False, use_graphs=False)
+    eng = SyncReplicasEngine(prog, st, collective=collective)
+    eng.run(20)
+    torch.cuda.synchronize()
+    recs = prog.read_log(0, 20)
+    out = {"params": st.params.cpu().numpy().copy(), "gs": st.global_step(), "first": recs[0].loss, "last": recs[-1].loss}
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+@pytest.mark.parametrize("collective", ["all_reduce", "reduce_scatter"])
+def test_two_ranks_sync_on_one_gpu(collective):
+    a, b = run_ranks(_sync_gpu, 2, collective)
+    assert (a["params"] == b["params"]).all()
+    assert a["gs"] == b["gs"] == 21
+    assert a["last"] < a["first"] - 0.3
+
+
+def _async_gpu(rank, world, port):
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterServerEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=100, test_size=300, seed=rank)
+    st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, lr=0.5)
+    st.initialize(seed=3)
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=rank), 100, [100], fused_update=False, gs_inc=0,
+                      post_update_accuracy=False)
+    eng = AsyncParameterServerEngine(prog, st, num_shards=1, staleness=2)
+    eng.run(30)
+    eng.sync_params()
+    recs = prog.read_log(0, 30)
+    eng.finish()
+    dist.barrier()
+    out = {"gs": st.global_step(), "first": recs[0].loss, "last": recs[-1].loss, "applied": eng.updates_applied_here}
+    dist.destroy_process_group()
+    return out
+
+
+def test_three_ranks_async_on_one_gpu():
+    res = run_ranks(_async_gpu, 3)
+    assert res[0]["gs"] == 1 + 3 * 30 and res[0]["applied"] == 3 * 30
+    assert all(r["last"] < r["first"] - 0.3 for r in res)
+
+
+def test_host_backend_with_gpu_worker():
+    ps_port, w_port = free_port(), free_port()
+    args = ["--ps_backend=host", "--ps_hosts=127.0.0.1:%d" % ps_port, "--worker_hosts=127.0.0.1:%d" % w_port,
+            "--train_steps=25"] + [a for a in COMMON if not a.startswith("--device")] + ["--device=gpu"]
+    ps = _launch(["--job_name=ps", "--task_index=0"] + args)
+    w = _launch(["--job_name=worker", "--task_index=0"] + args)
+    lines = _finish(w)
+    _finish(ps)
+    st = _steps(lines)
+    assert [s[1] for s in st] == list(range(1, 26))
+    assert st[-1][2] < st[0][2] - 0.3
