@@ -293,7 +293,7 @@ DTF_EXPORT int dtf_small_gemm(const DtfSmallGemmArgs* a, hipStream_t s) {
 // One 16x16 tile per wave, four tiles per workgroup; one extra workgroup runs the step tail.
 // --------------------------------------------------------------------------------------
 #ifndef DTF_WGRAD_CH
-#define DTF_WGRAD_CH 4
+#define DTF_WGRAD_CH 7
 #endif
 
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
