@@ -113,6 +113,17 @@ struct DtfGemmArgs {
   unsigned a_bytes, b_bytes;
 };
 
+// A pre-validated launch sequence: the hand-scheduled step (what a graph partitioner + executor do
+// in the reference runtime).  One call enqueues every entry in order on `s`; stops at the first error
+// and returns  (entry index << 8) | error code.
+enum { DTF_OP_SMALL_GEMM = 1, DTF_OP_HEAD = 2, DTF_OP_WGRAD = 3, DTF_OP_TAIL = 4, DTF_OP_GEMM_TILED = 5 };
+struct DtfScheduleEntry {
+  int op;
+  int flag;          // DTF_OP_TAIL: init_only
+  const void* args;  // the op's argument struct
+};
+DTF_EXPORT int dtf_run_schedule(const DtfScheduleEntry* entries, int n, hipStream_t s);
+
 DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s);
 DTF_EXPORT int dtf_gather_cast_transpose(const float* src, const int* rows, void* dst, void* dstT, int M, int N, int lds_,
                                          int ldd, int ldt, int dtype, hipStream_t s);

@@ -169,4 +169,21 @@ DTF_EXPORT int dtf_truncated_normal(float* out, int64_t n, float stddev, uint64_
   return dtf_check_launch();
 }
 
+DTF_EXPORT int dtf_run_schedule(const DtfScheduleEntry* entries, int n, hipStream_t s) {
+  if (!entries || n < 0) return DTF_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    int rc;
+    switch (entries[i].op) {
+      case DTF_OP_SMALL_GEMM: rc = dtf_small_gemm(static_cast<const DtfSmallGemmArgs*>(entries[i].args), s); break;
+      case DTF_OP_HEAD: rc = dtf_head(static_cast<const DtfHeadArgs*>(entries[i].args), s); break;
+      case DTF_OP_WGRAD: rc = dtf_wgrad_grouped(static_cast<const DtfWgradArgs*>(entries[i].args), s); break;
+      case DTF_OP_TAIL: rc = dtf_step_tail(static_cast<const DtfTailArgs*>(entries[i].args), entries[i].flag, s); break;
+      case DTF_OP_GEMM_TILED: rc = dtf_gemm_tiled(static_cast<const DtfGemmArgs*>(entries[i].args), s); break;
+      default: rc = DTF_ERR_ARG;
+    }
+    if (rc != DTF_OK) return (i << 8) | rc;
+  }
+  return DTF_OK;
+}
+
 DTF_EXPORT int dtf_kernels_abi_version() { return 1; }

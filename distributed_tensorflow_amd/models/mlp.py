@@ -78,6 +78,8 @@ class MLPProgram:
         self.ridx = torch.zeros((2, 2 * batch), dtype=i32, device=dev)
         self.steps_enqueued = 0           # host mirror of state[1] (counts enqueued, not necessarily finished, steps)
         self._graphs: Dict = {}
+        self._call_cache: Dict = {}
+        self._schedules: Dict = {}
         self._eval_buf: Dict = {}
         self._args = [self._build_args(0), self._build_args(1)] if self.is_cuda else None
         self._started = False
@@ -111,6 +113,16 @@ class MLPProgram:
         wgrad = ops.build_wgrad_args(items, lr=st.lr if self.fused else None, tail=self._tail(q))
         return {"head": head, "wgrad": wgrad, "items": items}
 
+    def _launch_cached(self, key, build):
+        """Argument structs of a launch are built once per (step parity, call site) and reused: the
+        eager path then costs one ctypes call per kernel."""
+        ent = self._call_cache.get(key)
+        if ent is None:
+            ent = build()
+            self._call_cache[key] = ent
+        fn, arg = ent
+        ops._lib.check(fn(arg, ops._lib.stream_handle()), key[0])
+
     # ------------------------------------------------------------------ one step
     def start(self) -> None:
         """Select the rows of the first batch (runs once, before the first step)."""
@@ -125,27 +137,47 @@ class MLPProgram:
             self._tail_cpu(q, init_only=True)
         self._started = True
 
+    def _compute_schedule(self, q: int):
+        """The whole compute part of a step (forward, head, backward, weight gradients + tail) as one
+        native launch sequence; built once per step parity."""
+        sch = self._schedules.get(q)
+        if sch is None:
+            st, rows, L = self.state, self.ridx[q], ops._lib
+            entries = []
+            x = self.data.images
+            for l, name in enumerate(self.names):
+                entries.append((L.OP_SMALL_GEMM, ops.linear_fwd(x, st.var(f"{name}_w"), st.var(f"{name}_b"), True,
+                                                                rows if l == 0 else None, self.hact[l], self.R,
+                                                                _build_only=True), 0))
+                x = self.hact[l]
+            entries.append((L.OP_HEAD, self._args[q]["head"], 0))
+            for l in range(len(self.names) - 1, 0, -1):
+                entries.append((L.OP_SMALL_GEMM, ops.linear_bwd_data(self.dz[l], st.var(f"{self.names[l]}_w"),
+                                                                     self.hact[l - 1], self.dz[l - 1], self.B,
+                                                                     _build_only=True), 0))
+            entries.append((L.OP_WGRAD, self._args[q]["wgrad"], 0))
+            sch = L.Schedule(entries)
+            self._schedules[q] = sch
+        return sch
+
     def enqueue_step(self) -> None:
         """Enqueue one full training step on the current stream (no host synchronisation)."""
         q = self.steps_enqueued & 1
         st, rows = self.state, self.ridx[q]
-        x = self.data.images
-        for l, name in enumerate(self.names):
-            ops.linear_fwd(x, st.var(f"{name}_w"), st.var(f"{name}_b"), relu=True, rows=rows if l == 0 else None,
-                           out=self.hact[l], m=self.R)
-            x = self.hact[l]
         if self.is_cuda:
-            ops.head(self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B,
-                     args=self._args[q]["head"])
+            self._compute_schedule(q).run()
         else:
+            x = self.data.images
+            for l, name in enumerate(self.names):
+                ops.linear_fwd(x, st.var(f"{name}_w"), st.var(f"{name}_b"), relu=True, rows=rows if l == 0 else None,
+                               out=self.hact[l], m=self.R)
+                x = self.hact[l]
             ops.head(self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B, self.loss_mode,
                      rows=rows, dz2=self.dz2, dz1=self.dz[-1], loss_part=self.loss_part, correct_part=self.correct_part,
                      post_part=self.post_part)
-        for l in range(len(self.names) - 1, 0, -1):
-            ops.linear_bwd_data(self.dz[l], st.var(f"{self.names[l]}_w"), act=self.hact[l - 1], out=self.dz[l - 1], m=self.B)
-        if self.is_cuda:
-            ops.wgrad_grouped(self._args[q]["items"], args=self._args[q]["wgrad"])
-        else:
+            for l in range(len(self.names) - 1, 0, -1):
+                ops.linear_bwd_data(self.dz[l], st.var(f"{self.names[l]}_w"), act=self.hact[l - 1], out=self.dz[l - 1],
+                                    m=self.B)
             ops.wgrad_grouped(self._wgrad_items(q), lr=st.lr if self.fused else None)
             self._tail_cpu(q, init_only=False)
         if self.after_compute is not None:

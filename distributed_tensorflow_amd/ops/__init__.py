@@ -41,7 +41,7 @@ def _same_device(*ts):
 
 
 # --------------------------------------------------------------------------- linear
-def linear_fwd(x, w, b=None, relu=False, rows=None, out=None, m=None):
+def linear_fwd(x, w, b=None, relu=False, rows=None, out=None, m=None, _build_only=False):
     """``out[:m] = act(x[rows[:m]] @ w + b)``; K1 of the reference graph (distributed.py:78-79)."""
     K, N = w.shape
     M = m if m is not None else (rows.shape[0] if rows is not None else x.shape[0])
@@ -62,18 +62,29 @@ def linear_fwd(x, w, b=None, relu=False, rows=None, out=None, m=None):
         raise ValueError("linear_fwd: rows shorter than m")
     if rows is None and x.shape[0] < M:
         raise ValueError("linear_fwd: x has fewer rows than m")
+    if b is not None and b.numel() != N:
+        raise ValueError("linear_fwd: bias size mismatch")
     a = _lib.SmallGemmArgs(A=_f32c(x, "x").data_ptr(), a_rows=_lib.ptr(None if rows is None else _i32c(rows, "rows")),
                            B=_f32c(w, "w").data_ptr(), bias=_lib.ptr(None if b is None else _f32c(b, "b")), mask=None,
                            C=_f32c(out, "out").data_ptr(), M=M, N=N, K=K, lda=x.stride(0), ldb=w.stride(0),
                            ldc=out.stride(0), ldmask=0, relu=int(bool(relu)), b_transposed=0,
                            a_bytes=_lib.span_bytes(x), b_bytes=_lib.span_bytes(w))
-    if b is not None and b.numel() != N:
-        raise ValueError("linear_fwd: bias size mismatch")
+    if _build_only:
+        return a
     _lib.check(_lib.kernels().dtf_small_gemm(C.byref(a), _lib.stream_handle()), "linear_fwd")
     return out
 
 
-def linear_bwd_data(dy, w, act=None, out=None, m=None):
+def linear_fwd_call(x, w, b, relu, rows, out, m):
+    """(launcher, validated argument struct) of a forward launch, for callers that replay it every step."""
+    return _lib.kernels().dtf_small_gemm, linear_fwd(x, w, b, relu, rows, out, m, _build_only=True)
+
+
+def linear_bwd_data_call(dy, w, act, out, m):
+    return _lib.kernels().dtf_small_gemm, linear_bwd_data(dy, w, act, out, m, _build_only=True)
+
+
+def linear_bwd_data(dy, w, act=None, out=None, m=None, _build_only=False):
     """``out[:m] = (dy[:m] @ w^T) * (act > 0)``; MatMul grad + ReluGrad (K7)."""
     K, N = w.shape          # w is the forward weight [in, out]; dy is [M, out]
     M = m if m is not None else dy.shape[0]
@@ -97,6 +108,8 @@ def linear_bwd_data(dy, w, act=None, out=None, m=None):
                            M=M, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0),
                            ldmask=0 if act is None else act.stride(0), relu=0, b_transposed=1,
                            a_bytes=_lib.span_bytes(dy), b_bytes=_lib.span_bytes(w))
+    if _build_only:
+        return a
     _lib.check(_lib.kernels().dtf_small_gemm(C.byref(a), _lib.stream_handle()), "linear_bwd_data")
     return out
 

@@ -72,6 +72,29 @@ class GemmArgs(C.Structure):
                 ("b_bytes", C.c_uint)]
 
 
+OP_SMALL_GEMM, OP_HEAD, OP_WGRAD, OP_TAIL, OP_GEMM_TILED = 1, 2, 3, 4, 5
+
+
+class ScheduleEntry(C.Structure):
+    _fields_ = [("op", C.c_int), ("flag", C.c_int), ("args", C.c_void_p)]
+
+
+class Schedule:
+    """A launch sequence handed to the native executor in one call.  Keeps the argument structs alive."""
+
+    def __init__(self, entries):
+        self._keep = [a for _, a, _ in entries]
+        self.n = len(entries)
+        self.array = (ScheduleEntry * self.n)()
+        for i, (op, arg, flag) in enumerate(entries):
+            self.array[i].op, self.array[i].flag, self.array[i].args = op, flag, C.addressof(arg)
+
+    def run(self):
+        rc = kernels().dtf_run_schedule(self.array, self.n, stream_handle())
+        if rc:
+            raise RuntimeError(f"schedule entry {rc >> 8} refused its launch ({ERR_NAMES.get(rc & 0xff, rc & 0xff)})")
+
+
 def span_bytes(t) -> int:
     """Bytes addressable from ``t.data_ptr()`` for a row-major 2-D (or 1-D) tensor view."""
     if t.dim() == 1:
@@ -99,10 +122,11 @@ def _declare_kernels(lib):
     lib.dtf_truncated_normal.argtypes = [vp, i64, f32, u64, u64, vp]
     lib.dtf_accumulate.argtypes = [vp, vp, i64, f32, f32, vp]
     lib.dtf_gemm_tiled.argtypes = [C.POINTER(GemmArgs), vp]
+    lib.dtf_run_schedule.argtypes = [C.POINTER(ScheduleEntry), i32, vp]
     lib.dtf_gather_cast_transpose.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     for name in ("dtf_small_gemm", "dtf_wgrad_grouped", "dtf_head", "dtf_step_tail", "dtf_sgd_apply", "dtf_adam_apply",
                  "dtf_truncated_normal", "dtf_accumulate", "dtf_kernels_abi_version", "dtf_gemm_tiled",
-                 "dtf_gather_cast_transpose"):
+                 "dtf_gather_cast_transpose", "dtf_run_schedule"):
         getattr(lib, name).restype = i32
 
 

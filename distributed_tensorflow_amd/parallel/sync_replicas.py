@@ -22,6 +22,7 @@ from arrival times exchanged in a small all-gather, which needs the host.
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Callable, Optional
 
@@ -40,7 +41,8 @@ ALLREDUCE_BELOW_BYTES = 1 << 20
 class SyncReplicasEngine:
     def __init__(self, program, state: ShardedState, group=None, replicas_to_aggregate: Optional[int] = None,
                  total_num_replicas: Optional[int] = None, collective: str = "auto",
-                 arrival_delay: Optional[Callable[[int], float]] = None, force_collectives: bool = False):
+                 arrival_delay: Optional[Callable[[int], float]] = None, force_collectives: bool = False,
+                 capture_collectives: Optional[bool] = None):
         self.program, self.state = program, state
         self.world = state.world_size
         self.total = total_num_replicas if total_num_replicas is not None else self.world
@@ -52,6 +54,12 @@ class SyncReplicasEngine:
         # force_collectives: issue the collectives even on a one-rank group (exercises the RCCL calls
         # and their hipGraph capture on a single-GPU box)
         self.use_coll = self.world > 1 or force_collectives
+        # Steps that contain collectives are launched eagerly unless asked otherwise: with several ranks
+        # the collective's latency, not the host, bounds the step, and an eager launch cannot wedge a
+        # graph replay if one rank falls over.  DTF_CAPTURE_COLLECTIVES=1 (or the argument) captures them.
+        if capture_collectives is None:
+            capture_collectives = os.environ.get("DTF_CAPTURE_COLLECTIVES", "0") == "1" or force_collectives
+        self.capture_collectives = capture_collectives
         self.coll = Collectives(group) if self.use_coll else None
         if collective == "auto":
             small = state.nbytes() < ALLREDUCE_BELOW_BYTES and state.optimizer == "sgd"
@@ -91,6 +99,8 @@ class SyncReplicasEngine:
     def run(self, n_steps: int, graph_steps: int = 64) -> None:
         """Run ``n_steps`` aggregated updates (each rank contributes as the R/num_workers ratio dictates)."""
         if self.fast:
+            if self.use_coll and not self.capture_collectives:
+                self.program.use_graphs = False
             if self.use_coll and self.program.use_graphs:
                 try:
                     self.program.run(n_steps, graph_steps)

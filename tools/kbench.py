@@ -79,6 +79,11 @@ def main():
     def step():
         fwd(); head(); wgrad()
 
+    import time
+    prog.use_graphs = False
+    prog.run(50); torch.cuda.synchronize()
+    t0 = time.perf_counter(); prog.run(2000); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"eager step: host enqueue {(t1 - t0) / 2000 * 1e6:.1f} us/step, end-to-end {(t2 - t0) / 2000 * 1e6:.1f} us/step")
     for name, fn in [("empty(4 elems)", empty), ("fwd", fwd), ("head", head), ("wgrad+sgd+tail", wgrad),
                      ("wgrad+sgd", wgrad_notail), ("wgrad store", wgrad_store), ("tail only", tail_only),
                      ("sgd flat 79.5k", sgd), ("full step", step)]:
