@@ -61,7 +61,12 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer=optimizer, lr=lr)
     state.initialize(seed=1234)                      # same seed everywhere == chief init + broadcast
     data = DeviceDataset(ds.train, device, shuffle_seed=1000 + rank)
-    fused = world == 1 and optimizer == "sgd" and not wide
+    force = bool(getattr(args, "force_collectives", False)) and world == 1 and device.type == "cuda"
+    if force and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    fused = world == 1 and optimizer == "sgd" and not wide and not force
     dtype_name = args.dtype or "fp32"
     if wide:
         cdtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
@@ -70,7 +75,8 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     else:
         prog = MLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, fused_update=fused,
                           post_update_accuracy=not args.no_post_update_accuracy, gs_inc=1)
-    engine = SyncReplicasEngine(prog, state, collective=args.collective)
+    engine = SyncReplicasEngine(prog, state, collective=args.collective, force_collectives=force,
+                                capture_collectives=False if force else None)
     graph_steps = args.graph_steps or 64
     _sync_all(device, world)
     engine.run(args.warmup, graph_steps) if args.warmup > 0 else None
@@ -92,7 +98,8 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
                    "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
                    "parallelism": f"dp{world} sync_replicas R={world}, ps state sharded over {world} GPU(s)",
                    "optimizer": optimizer, "loss": "reference (softmax applied twice)", "mode": "sync",
-                   "collective": engine.collective if world > 1 else "none",
+                   "collective": engine.collective if (world > 1 or force) else "none",
+                   "native_rccl": engine.native_comm is not None,
                    "post_update_accuracy_pass": not args.no_post_update_accuracy,
                    "hip_graph": bool(prog.use_graphs), "params": state.layout.used},
         "final_loss": last.loss,

@@ -116,7 +116,37 @@ struct DtfGemmArgs {
 // A pre-validated launch sequence: the hand-scheduled step (what a graph partitioner + executor do
 // in the reference runtime).  One call enqueues every entry in order on `s`; stops at the first error
 // and returns  (entry index << 8) | error code.
-enum { DTF_OP_SMALL_GEMM = 1, DTF_OP_HEAD = 2, DTF_OP_WGRAD = 3, DTF_OP_TAIL = 4, DTF_OP_GEMM_TILED = 5 };
+enum { DTF_OP_SMALL_GEMM = 1, DTF_OP_HEAD = 2, DTF_OP_WGRAD = 3, DTF_OP_TAIL = 4, DTF_OP_GEMM_TILED = 5, DTF_OP_UPDATE = 6 };
+
+// Gradient aggregation + optimizer + parameter redistribution of one synchronous step.
+enum { DTF_UPDATE_LOCAL = 0, DTF_UPDATE_ALLREDUCE = 1, DTF_UPDATE_SHARDED = 2 };
+struct DtfUpdateArgs {
+  void* comm;             // RCCL communicator (dtf_comm_init); null for DTF_UPDATE_LOCAL
+  float* params;          // flat parameter replica [total]
+  float* grads;           // flat gradients [total]
+  float* rs_out;          // [shard_elems] reduce-scatter output (sharded mode)
+  float* m;               // Adam state of the owned slice
+  float* v;
+  int* step;              // device counter of applied updates (Adam bias correction)
+  int64_t total;
+  int64_t shard_offset;
+  int64_t shard_elems;
+  int mode;
+  int optimizer;          // 0 = SGD, 1 = Adam
+  float lr, grad_scale, beta1, beta2, eps;
+  int pad_;
+};
+DTF_EXPORT int dtf_run_update(const DtfUpdateArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_int_add(int* p, int v, hipStream_t s);
+DTF_EXPORT int dtf_comm_load(const char* path);
+DTF_EXPORT int dtf_comm_unique_id(char* out128);
+DTF_EXPORT void* dtf_comm_init(const char* id128, int nranks, int rank, int* rc_out);
+DTF_EXPORT int dtf_comm_destroy(void* comm);
+DTF_EXPORT const char* dtf_comm_error_string(int rc);
+DTF_EXPORT int dtf_comm_all_reduce_f32(void* comm, float* buf, int64_t count, hipStream_t s);
+DTF_EXPORT int dtf_comm_reduce_scatter_f32(void* comm, const float* send, float* recv, int64_t recvcount, hipStream_t s);
+DTF_EXPORT int dtf_comm_all_gather_f32(void* comm, const float* send, float* recv, int64_t sendcount, hipStream_t s);
+DTF_EXPORT int dtf_comm_broadcast_bytes(void* comm, void* buf, int64_t nbytes, int root, hipStream_t s);
 struct DtfScheduleEntry {
   int op;
   int flag;          // DTF_OP_TAIL: init_only

@@ -179,6 +179,7 @@ DTF_EXPORT int dtf_run_schedule(const DtfScheduleEntry* entries, int n, hipStrea
       case DTF_OP_WGRAD: rc = dtf_wgrad_grouped(static_cast<const DtfWgradArgs*>(entries[i].args), s); break;
       case DTF_OP_TAIL: rc = dtf_step_tail(static_cast<const DtfTailArgs*>(entries[i].args), entries[i].flag, s); break;
       case DTF_OP_GEMM_TILED: rc = dtf_gemm_tiled(static_cast<const DtfGemmArgs*>(entries[i].args), s); break;
+      case DTF_OP_UPDATE: rc = dtf_run_update(static_cast<const DtfUpdateArgs*>(entries[i].args), s); break;
       default: rc = DTF_ERR_ARG;
     }
     if (rc != DTF_OK) return (i << 8) | rc;

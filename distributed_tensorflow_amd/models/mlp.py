@@ -80,6 +80,7 @@ class MLPProgram:
         self._graphs: Dict = {}
         self._call_cache: Dict = {}
         self._schedules: Dict = {}
+        self.schedule_tail_entries = []   # appended by the engine: the native update entry of each step
         self._eval_buf: Dict = {}
         self._args = [self._build_args(0), self._build_args(1)] if self.is_cuda else None
         self._started = False
@@ -156,6 +157,7 @@ class MLPProgram:
                                                                      self.hact[l - 1], self.dz[l - 1], self.B,
                                                                      _build_only=True), 0))
             entries.append((L.OP_WGRAD, self._args[q]["wgrad"], 0))
+            entries.extend(self.schedule_tail_entries)
             sch = L.Schedule(entries)
             self._schedules[q] = sch
         return sch

@@ -47,6 +47,7 @@ class WideMLPProgram(MLPProgram):
         self.w = [None if T == torch.float32 else z(dims[i], dims[i + 1]) for i in range(len(hidden))]
         self.w_t = [z(dims[i + 1], dims[i]) for i in range(len(hidden))]
         self.refresh_compute_copies()
+        del self.schedule_tail_entries      # this program enqueues op by op; the engine then uses after_compute
 
     def _build_args(self, q: int):
         st = self.state

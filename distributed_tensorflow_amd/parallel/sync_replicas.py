@@ -81,8 +81,43 @@ class SyncReplicasEngine:
             raise ValueError("program.gs_inc must be 1 on the fast path and 0 when the engine counts updates itself")
         if program.fused and not (self.fast and self.world == 1):
             raise ValueError("a program with the update fused into its epilogue only fits one rank with R == 1")
+        self.native_comm = None
+        self._update_schedule = None
         if self.fast and not program.fused:
             program.after_compute = self._aggregate_and_apply if self.use_coll else (lambda: state.apply_shard(None, 1.0))
+            if state.device.type == "cuda":
+                self._install_native_update(group)
+
+    def _install_native_update(self, group) -> None:
+        """GPU fast path: aggregation + optimizer + redistribution become ONE entry of the native step
+        schedule (RCCL called from C++ on the compute stream).  Falls back to the torch.distributed
+        collectives above if the native communicator cannot be created."""
+        from . import native_comm as nc
+        from ..ops import _lib
+        st, prog = self.state, self.program
+        if not nc.enabled():
+            return
+        if self.use_coll:
+            if self.coll.backend != "nccl" or group is not None:
+                return                      # gloo rehearsals and sub-groups keep the torch path
+            try:
+                self.native_comm = nc.NativeComm(self.coll.rank, self.coll.world, st.device)
+            except (RuntimeError, OSError) as e:
+                import warnings
+                warnings.warn(f"native RCCL communicator unavailable ({e}); using torch.distributed collectives")
+                return
+            mode = nc.UPDATE_ALLREDUCE if self.collective == "all_reduce" else nc.UPDATE_SHARDED
+        else:
+            mode = nc.UPDATE_LOCAL
+        self._update_args = nc.make_update_args(st, mode, 1.0 / self.R, self.native_comm, self._rs_out)
+        entry = (nc.OP_UPDATE, self._update_args, 0)
+        if hasattr(prog, "schedule_tail_entries"):
+            prog.schedule_tail_entries.append(entry)      # same native call as the compute kernels
+            prog._schedules.clear()
+            prog.after_compute = None
+        else:
+            self._update_schedule = _lib.Schedule([entry])
+            prog.after_compute = self._update_schedule.run
 
     # ------------------------------------------------------------------ fast path (R == num_workers)
     def _aggregate_and_apply(self) -> None:

@@ -163,3 +163,36 @@ def test_gpu_cli_single_worker_runs_hip_path(capsys):
     assert sum("validation accuracy" in l for l in out) == 3
     assert _lib._kernels is not None            # the HIP library did the work
     F.FLAGS.reset()
+
+
+@pytest.mark.gpu
+def test_gpu_native_rccl_update_entry_is_used_and_matches_torch_collectives(monkeypatch):
+    """The engine's GPU fast path must run through the native RCCL communicator (one-rank group here);
+    with DTF_NATIVE_COMM=0 the torch.distributed path must give the same trajectory."""
+    import torch.distributed as dist
+    from dist_utils import free_port
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=200, test_size=300, seed=5)
+
+    def make(native, coll, optimizer):
+        monkeypatch.setenv("DTF_NATIVE_COMM", "1" if native else "0")
+        st = build_mlp_state(784, [100], 10, "cuda", lr=0.3 if optimizer == "sgd" else 1e-3, optimizer=optimizer)
+        st.initialize(seed=11)
+        prog = MLPProgram(st, DeviceDataset(ds.train, "cuda", shuffle_seed=5), 100, [100], fused_update=False)
+        eng = SyncReplicasEngine(prog, st, collective=coll, force_collectives=True, capture_collectives=False)
+        eng.run(16)
+        torch.cuda.synchronize()
+        return st, prog, eng
+
+    for coll, optimizer in (("all_reduce", "sgd"), ("reduce_scatter", "sgd"), ("reduce_scatter", "adam")):
+        st_n, prog_n, eng_n = make(True, coll, optimizer)
+        st_t, prog_t, eng_t = make(False, coll, optimizer)
+        assert eng_n.native_comm is not None and prog_n.after_compute is None       # update rides in the native schedule
+        assert eng_t.native_comm is None and prog_t.after_compute is not None
+        torch.testing.assert_close(st_n.params, st_t.params, rtol=1e-6, atol=1e-7)
+        assert st_n.global_step() == st_t.global_step() == 17
+        if optimizer == "adam":
+            assert int(st_n.state[2]) == 16
