@@ -52,8 +52,18 @@ def parse_args():
 
 def main():
     args = parse_args()
-    from distributed_tensorflow_amd.benchmarks import run_benchmark
-    result = run_benchmark(args)
+    # Libraries (RCCL prints a version banner at communicator creation) must not write to the stream
+    # that carries the result: everything except the final JSON line goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        from distributed_tensorflow_amd.benchmarks import run_benchmark
+        result = run_benchmark(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
     if result is not None:
         print(json.dumps(result), flush=True)
 
