@@ -92,6 +92,36 @@ struct DtfHeadArgs {
   int pad_;
 };
 
+// Two-launch training step of the one-hidden-layer network (mlp2_fused.hip): launch 1 = hidden layer
+// + per-column-tile partial logits, launch 2 = loss/accuracy records, softmax gradient, both weight
+// gradients (optionally the SGD update) and the step tail.  One struct drives both launches.
+#define DTF_WLOG_INTS 64     // ints per record of the wide log: [0] global_step fetched, [1] local step,
+                             // [4+rb] loss-sum bits, [20+rb] correct, [36+rb] post-update correct of row block rb
+struct DtfMlp2Args {
+  const float* X;           // [n, In] dataset rows (ldx)
+  const int* ridx;          // [ridx_len] dataset row of each logical row: [0,B) training batch, [B,R) accuracy-only rows
+  const float* labels;      // [n, C]
+  float* H;                 // [>=R, ldh] hidden activations (written by launch 1)
+  float* zpart;             // [R16*16][16][8] partial logits: (row, class, hidden column tile); zero-initialised
+  float* labg;              // [R16*16][16] label rows of the step's logical rows, gathered by launch 1 (zero padded)
+  float* W2s;               // [Hd*C] copy of W2 taken by launch 1 (launch 2 overwrites W2 while others read it)
+  int* ctr_snap;            // [2] copy of state[0..1] taken by launch 1
+  float* W1; float* b1; float* W2; float* b2;         // parameters; updated in place when mode == 1
+  float* dW1; float* db1; float* dW2; float* db2;     // gradients out when mode == 0
+  int* wlog;                // [log_cap][DTF_WLOG_INTS]
+  int In, Hd, C, B, R;
+  int ldx, ldh;
+  int ridx_len;             // allocated entries behind ridx (multiple of 16, >= the padded row count)
+  int loss_mode;
+  int mode;                 // 0: store gradients, 1: theta -= lr * grad
+  int log_cap;
+  float lr, inv_b;
+  unsigned x_bytes;         // bytes addressable from X
+  DtfTailArgs tail;         // counters + next batch rows (its log / partial arrays are not used)
+};
+DTF_EXPORT int dtf_mlp2_fwd(const DtfMlp2Args* a, hipStream_t s);
+DTF_EXPORT int dtf_mlp2_bwd(const DtfMlp2Args* a, hipStream_t s);
+
 // C[M,N] = A[M,K] . B[N,K]^T with both operands k-contiguous (see gemm_tiled.hip).
 // dtype: 0 = fp32, 1 = bf16 (fp32 accumulate).  epilogue: 0 forward (+bias, ReLU, optional transposed copy Ct
 // and fp32 copy C32), 1 backward (mask > 0, optional Ct), 2 weight gradient (C is always fp32; bias_out = row
@@ -116,7 +146,8 @@ struct DtfGemmArgs {
 // A pre-validated launch sequence: the hand-scheduled step (what a graph partitioner + executor do
 // in the reference runtime).  One call enqueues every entry in order on `s`; stops at the first error
 // and returns  (entry index << 8) | error code.
-enum { DTF_OP_SMALL_GEMM = 1, DTF_OP_HEAD = 2, DTF_OP_WGRAD = 3, DTF_OP_TAIL = 4, DTF_OP_GEMM_TILED = 5, DTF_OP_UPDATE = 6 };
+enum { DTF_OP_SMALL_GEMM = 1, DTF_OP_HEAD = 2, DTF_OP_WGRAD = 3, DTF_OP_TAIL = 4, DTF_OP_GEMM_TILED = 5, DTF_OP_UPDATE = 6,
+       DTF_OP_MLP2_FWD = 7, DTF_OP_MLP2_BWD = 8 };
 
 // Gradient aggregation + optimizer + parameter redistribution of one synchronous step.
 enum { DTF_UPDATE_LOCAL = 0, DTF_UPDATE_ALLREDUCE = 1, DTF_UPDATE_SHARDED = 2 };

@@ -18,6 +18,7 @@ only to count correct predictions.  That reproduces the reference's second
 """
 from __future__ import annotations
 
+import os
 import struct
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
@@ -49,6 +50,8 @@ def hidden_names(n_hidden: int) -> List[str]:
 
 
 class MLPProgram:
+    _supports_mlp2 = True
+
     def __init__(self, state: ShardedState, dataset: DeviceDataset, batch: int, hidden: Sequence[int], classes: int = 10,
                  loss_mode: int = ops.LOSS_REFERENCE, fused_update: bool = True, post_update_accuracy: bool = True,
                  gs_inc: int = 1, log_capacity: int = 2048, use_graphs: Optional[bool] = None):
@@ -75,7 +78,20 @@ class MLPProgram:
         self.post_part = torch.zeros(self.nblk, dtype=i32, device=dev)
         self.log_cap = log_capacity
         self.log = torch.zeros((log_capacity, 4), dtype=i32, device=dev)
-        self.ridx = torch.zeros((2, 2 * batch), dtype=i32, device=dev)
+        # row index tables (one per step parity), padded to whole 16-row blocks: kernels read the padding unguarded
+        self.ridx = torch.zeros((2, max(128, (2 * batch + 15) // 16 * 16)), dtype=i32, device=dev)
+        # Two-launch step (csrc/kernels/mlp2_fused.hip) for the reference shape; DTF_FUSED_STEP=0 selects the
+        # general three-launch sequence for A/B measurements.
+        in_dim = state.var(f"{self.names[0]}_w").shape[0]
+        self.fused2 = (self.is_cuda and type(self)._supports_mlp2 and os.environ.get("DTF_FUSED_STEP", "1") != "0"
+                       and ops.mlp2_eligible(in_dim, self.hidden, classes, batch))
+        if self.fused2:
+            r16 = (self.R + 15) // 16
+            self.zpart = torch.zeros(r16 * 16 * 16 * 8, dtype=f32, device=dev)
+            self.labg = torch.zeros(r16 * 16 * 16, dtype=f32, device=dev)
+            self.w2_snap = torch.zeros(self.hidden[0] * classes, dtype=f32, device=dev)
+            self.ctr_snap = torch.zeros(2, dtype=i32, device=dev)
+            self.wlog = torch.zeros((log_capacity, ops._lib.WLOG_INTS), dtype=i32, device=dev)
         self.steps_enqueued = 0           # host mirror of state[1] (counts enqueued, not necessarily finished, steps)
         self._graphs: Dict = {}
         self._call_cache: Dict = {}
@@ -112,7 +128,18 @@ class MLPProgram:
                                    loss_part=self.loss_part, correct_part=self.correct_part, post_part=self.post_part)
         items = self._wgrad_items(q)
         wgrad = ops.build_wgrad_args(items, lr=st.lr if self.fused else None, tail=self._tail(q))
-        return {"head": head, "wgrad": wgrad, "items": items}
+        out = {"head": head, "wgrad": wgrad, "items": items}
+        if self.fused2:
+            tail = ops.make_tail(st.state, ridx_cur=self.ridx[q], ridx_next=self.ridx[1 - q], perm=self.data.perm,
+                                 batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
+            tail.log_cap = self.log_cap
+            g = (lambda n: None) if self.fused else st.grad
+            out["mlp2"] = ops.build_mlp2_args(
+                self.data.images, self.ridx[q], self.data.labels, self.hact[0], self.zpart, self.labg, self.w2_snap, self.ctr_snap,
+                st.var("hid_w"), st.var("hid_b"), st.var("sm_w"), st.var("sm_b"), self.wlog, self.B, self.R,
+                self.loss_mode, tail, lr=st.lr if self.fused else None, dw1=g("hid_w"), db1=g("hid_b"), dw2=g("sm_w"),
+                db2=g("sm_b"))
+        return out
 
     def _launch_cached(self, key, build):
         """Argument structs of a launch are built once per (step parity, call site) and reused: the
@@ -146,6 +173,11 @@ class MLPProgram:
             st, rows, L = self.state, self.ridx[q], ops._lib
             entries = []
             x = self.data.images
+            if self.fused2:
+                entries = [(L.OP_MLP2_FWD, self._args[q]["mlp2"], 0), (L.OP_MLP2_BWD, self._args[q]["mlp2"], 0)]
+                entries.extend(self.schedule_tail_entries)
+                sch = self._schedules[q] = L.Schedule(entries)
+                return sch
             for l, name in enumerate(self.names):
                 entries.append((L.OP_SMALL_GEMM, ops.linear_fwd(x, st.var(f"{name}_w"), st.var(f"{name}_b"), True,
                                                                 rows if l == 0 else None, self.hact[l], self.R,
@@ -207,7 +239,7 @@ class MLPProgram:
             rows = off.to(torch.int32)
         dst = self.ridx[q] if init_only else self.ridx[1 - q]
         prev = rows if init_only else self.ridx[q][:self.B].clone()
-        dst[self.B:] = prev
+        dst[self.B:2 * self.B] = prev
         dst[:self.B] = rows
 
     # ------------------------------------------------------------------ multi-step execution
@@ -249,7 +281,7 @@ class MLPProgram:
         """Records of local steps ``[first, first+count)`` (0-based).  Synchronises with the device."""
         if count > self.log_cap:
             raise ValueError("asked for more records than the log ring holds")
-        log = self.log.cpu()
+        log = self._log_host()
         out = []
         for s in range(first_local_step, first_local_step + count):
             rec = log[s % self.log_cap]
@@ -262,6 +294,30 @@ class MLPProgram:
                 nxt = log[(first_local_step + i + 1) % self.log_cap]
                 r.post_correct = int(nxt[2])
         return out
+
+    def _log_host(self) -> torch.Tensor:
+        """The log ring on the host as ``[capacity, 4]`` int32 records {loss bits, correct, post, global_step}.
+        The two-launch step logs per-row-block partial sums; they are folded here in a fixed order."""
+        if not self.fused2:
+            return self.log.cpu()
+        w = self.wlog.cpu()
+        nb = (self.R + 15) // 16
+        loss = torch.zeros(w.shape[0], dtype=torch.float32)
+        parts = w[:, 4:4 + nb].contiguous().view(torch.float32)
+        for rb in range(nb):
+            loss = loss + parts[:, rb]
+        loss = loss * torch.tensor(1.0 / self.B, dtype=torch.float32)
+        out = torch.empty((w.shape[0], 4), dtype=torch.int32)
+        out[:, 0] = loss.view(torch.int32)
+        out[:, 1] = w[:, 20:20 + nb].sum(1).to(torch.int32)
+        out[:, 2] = w[:, 36:36 + nb].sum(1).to(torch.int32)
+        out[:, 3] = w[:, 0]
+        return out
+
+    def post_count_logged_at(self, local_step: int) -> int:
+        """Correct predictions on the accuracy-only rows of 0-based step ``local_step`` (= the batch of the
+        step before it, scored with the parameters that step produced)."""
+        return int(self._log_host()[local_step % self.log_cap][2])
 
     def post_correct_of_last_step(self) -> int:
         """Post-update accuracy count of the most recent step (needs one extra forward)."""

@@ -23,6 +23,8 @@ from .mlp import MLPProgram
 
 
 class WideMLPProgram(MLPProgram):
+    _supports_mlp2 = False
+
     def __init__(self, state: ShardedState, dataset: DeviceDataset, batch: int, hidden: Sequence[int], classes: int = 10,
                  loss_mode: int = ops.LOSS_REFERENCE, dtype: torch.dtype = torch.bfloat16, gs_inc: int = 1,
                  log_capacity: int = 2048, use_graphs: Optional[bool] = None):

@@ -72,7 +72,19 @@ class GemmArgs(C.Structure):
                 ("b_bytes", C.c_uint)]
 
 
-OP_SMALL_GEMM, OP_HEAD, OP_WGRAD, OP_TAIL, OP_GEMM_TILED = 1, 2, 3, 4, 5
+WLOG_INTS = 64
+
+
+class Mlp2Args(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ridx", C.c_void_p), ("labels", C.c_void_p), ("H", C.c_void_p), ("zpart", C.c_void_p),
+                ("labg", C.c_void_p), ("W2s", C.c_void_p), ("ctr_snap", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p),
+                ("b2", C.c_void_p), ("dW1", C.c_void_p), ("db1", C.c_void_p), ("dW2", C.c_void_p), ("db2", C.c_void_p),
+                ("wlog", C.c_void_p), ("In", C.c_int), ("Hd", C.c_int), ("C", C.c_int), ("B", C.c_int), ("R", C.c_int),
+                ("ldx", C.c_int), ("ldh", C.c_int), ("ridx_len", C.c_int), ("loss_mode", C.c_int), ("mode", C.c_int),
+                ("log_cap", C.c_int), ("lr", C.c_float), ("inv_b", C.c_float), ("x_bytes", C.c_uint), ("tail", TailArgs)]
+
+
+OP_SMALL_GEMM, OP_HEAD, OP_WGRAD, OP_TAIL, OP_GEMM_TILED, OP_UPDATE, OP_MLP2_FWD, OP_MLP2_BWD = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class ScheduleEntry(C.Structure):
@@ -122,11 +134,13 @@ def _declare_kernels(lib):
     lib.dtf_truncated_normal.argtypes = [vp, i64, f32, u64, u64, vp]
     lib.dtf_accumulate.argtypes = [vp, vp, i64, f32, f32, vp]
     lib.dtf_gemm_tiled.argtypes = [C.POINTER(GemmArgs), vp]
+    lib.dtf_mlp2_fwd.argtypes = [C.POINTER(Mlp2Args), vp]
+    lib.dtf_mlp2_bwd.argtypes = [C.POINTER(Mlp2Args), vp]
     lib.dtf_run_schedule.argtypes = [C.POINTER(ScheduleEntry), i32, vp]
     lib.dtf_gather_cast_transpose.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     for name in ("dtf_small_gemm", "dtf_wgrad_grouped", "dtf_head", "dtf_step_tail", "dtf_sgd_apply", "dtf_adam_apply",
                  "dtf_truncated_normal", "dtf_accumulate", "dtf_kernels_abi_version", "dtf_gemm_tiled",
-                 "dtf_gather_cast_transpose", "dtf_run_schedule"):
+                 "dtf_gather_cast_transpose", "dtf_run_schedule", "dtf_mlp2_fwd", "dtf_mlp2_bwd"):
         getattr(lib, name).restype = i32
 
 

@@ -154,8 +154,7 @@ class TrainingLoop:
         return time_end - time_begin
 
     def _post_of_previous(self, first_local_step: int) -> int:
-        log = self.prog.log[first_local_step % self.prog.log_cap].cpu()
-        return int(log[2])
+        return self.prog.post_count_logged_at(first_local_step)
 
 
 def build_worker(role: Optional[Role], device: torch.device, datasets, hidden_units: int, batch_size: int,

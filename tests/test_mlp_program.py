@@ -196,3 +196,42 @@ def test_gpu_native_rccl_update_entry_is_used_and_matches_torch_collectives(monk
         assert st_n.global_step() == st_t.global_step() == 17
         if optimizer == "adam":
             assert int(st_n.state[2]) == 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,batch,post,fused,loss", [
+    (100, 100, True, True, "reference"), (100, 100, True, False, "reference"), (50, 37, False, True, "standard"),
+    (128, 128, True, True, "reference"), (20, 16, True, False, "standard"), (72, 60, False, False, "reference")])
+def test_gpu_two_launch_step_matches_three_launch_step(monkeypatch, hidden, batch, post, fused, loss):
+    """mlp2_fused.hip (2 launches/step) against the general kernels (3 launches/step) and the CPU program:
+    same losses, counts, parameters (update fused) or gradients (gradients stored)."""
+    mode = ops.LOSS_REFERENCE if loss == "reference" else ops.LOSS_STANDARD
+    steps = 21
+
+    def make(device, two_launch):
+        monkeypatch.setenv("DTF_FUSED_STEP", "1" if two_launch else "0")
+        ds, st, prog, _ = _make(device, hidden=(hidden,), batch=batch, lr=0.2, post=post, loss_mode=mode, fused=fused,
+                                n_train=1000)
+        if not fused:
+            prog.after_compute = lambda: st.apply_shard(None, 1.0)      # plain SGD from the stored gradients
+        return st, prog
+
+    st_2, prog_2 = make("cuda", True)
+    st_3, prog_3 = make("cuda", False)
+    st_c, prog_c = make("cpu", False)
+    assert prog_2.fused2 and not prog_3.fused2
+    for p in (prog_2, prog_3, prog_c):
+        p.run(steps, graph_steps=4)
+    r2, r3, rc = prog_2.read_log(0, steps), prog_3.read_log(0, steps), prog_c.read_log(0, steps)
+    for a, b, c in zip(r2, r3, rc):
+        assert a.global_step == b.global_step == c.global_step and a.local_step == c.local_step
+        assert abs(a.loss - b.loss) < 2e-5 and abs(a.loss - c.loss) < 1e-4
+        assert abs(a.train_correct - c.train_correct) <= 1
+        if post and c.post_correct is not None:
+            assert abs(a.post_correct - c.post_correct) <= 1
+    torch.testing.assert_close(st_2.params, st_3.params, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(st_2.params.cpu(), st_c.params, rtol=1e-3, atol=1e-5)
+    if not fused:
+        torch.testing.assert_close(st_2.grads, st_3.grads, rtol=1e-4, atol=1e-7)
+    assert st_2.global_step() == steps + 1 and st_2.local_step() == steps
+    assert prog_2.post_correct_of_last_step() == prog_3.post_correct_of_last_step()

@@ -25,7 +25,7 @@ def _sync_worker(rank, world, port, R, collective, steps, slow_rank):
     fast = R == world
     prog = MLPProgram(st, DeviceDataset(ds.train, "cpu", shuffle_seed=100 + rank), B, [16], fused_update=False,
                       gs_inc=1 if fast else 0, post_update_accuracy=False)
-    delay = (lambda step: 0.15) if rank == slow_rank else (lambda step: 0.0)
+    delay = (lambda step: 0.4) if rank == slow_rank else (lambda step: 0.0)
     eng = SyncReplicasEngine(prog, st, replicas_to_aggregate=R, collective=collective, arrival_delay=None if fast else delay)
     eng.run(steps)
     out = {"params": {n: st.var(n).clone().numpy() for n in st.names()}, "gs": st.global_step(), "ls": st.local_step(),
