@@ -94,30 +94,34 @@ struct DtfHeadArgs {
 
 // Two-launch training step of the one-hidden-layer network (mlp2_fused.hip): launch 1 = hidden layer
 // + per-column-tile partial logits, launch 2 = loss/accuracy records, softmax gradient, both weight
-// gradients (optionally the SGD update) and the step tail.  One struct drives both launches.
+// gradients (optionally the SGD update), the step tail and the gather of the next batch.  One struct
+// drives both launches.  Per-step buffers rotate over three slots; `q` is the slot of this step.
 #define DTF_WLOG_INTS 64     // ints per record of the wide log: [0] global_step fetched, [1] local step,
                              // [4+rb] loss-sum bits, [20+rb] correct, [36+rb] post-update correct of row block rb
 struct DtfMlp2Args {
   const float* X;           // [n, In] dataset rows (ldx)
-  const int* ridx;          // [ridx_len] dataset row of each logical row: [0,B) training batch, [B,R) accuracy-only rows
   const float* labels;      // [n, C]
-  float* H;                 // [>=R, ldh] hidden activations (written by launch 1)
-  float* zpart;             // [R16*16][16][8] partial logits: (row, class, hidden column tile); zero-initialised
-  float* labg;              // [R16*16][16] label rows of the step's logical rows, gathered by launch 1 (zero padded)
+  float* Xg;                // [3][128][In] gathered batch rows (rows >= B stay zero); slot q = this step's batch, q-1 = the previous batch
+  float* labg;              // [3][16][128] gathered label rows, class-major, zero padded
+  int* ridx;                // [3][ridx_len] dataset row of each logical row ([0,B) batch, [B,2B) previous batch); host use
+  float* H;                 // [h_rows >= max(R,128), ldh] hidden activations (written by launch 1)
+  float* zpart;             // [16][R16*16][8] partial logits: (class, row, hidden column tile); zero-initialised
   float* W2s;               // [Hd*C] copy of W2 taken by launch 1 (launch 2 overwrites W2 while others read it)
   int* ctr_snap;            // [2] copy of state[0..1] taken by launch 1
   float* W1; float* b1; float* W2; float* b2;         // parameters; updated in place when mode == 1
   float* dW1; float* db1; float* dW2; float* db2;     // gradients out when mode == 0
   int* wlog;                // [log_cap][DTF_WLOG_INTS]
-  int In, Hd, C, B, R;
+  int In, Hd, C, B, R;      // R = B, or 2B with the accuracy-only rows
   int ldx, ldh;
-  int ridx_len;             // allocated entries behind ridx (multiple of 16, >= the padded row count)
+  int ridx_len;
+  int h_rows;
+  int q;                    // slot of this step, 0..2
   int loss_mode;
   int mode;                 // 0: store gradients, 1: theta -= lr * grad
   int log_cap;
   float lr, inv_b;
   unsigned x_bytes;         // bytes addressable from X
-  DtfTailArgs tail;         // counters + next batch rows (its log / partial arrays are not used)
+  DtfTailArgs tail;         // state, perm, n_train, gs_inc (its log / partial / ridx fields are not used)
 };
 DTF_EXPORT int dtf_mlp2_fwd(const DtfMlp2Args* a, hipStream_t s);
 DTF_EXPORT int dtf_mlp2_bwd(const DtfMlp2Args* a, hipStream_t s);

@@ -1,25 +1,29 @@
 // Two-launch training step of the reference network x -> relu(x W1 + b1) -> softmax(h W2 + b2)
 // (math: /root/reference/distributed.py:78-89 and its autodiff), exact fp32 MFMA throughout.
 //
-// The three-launch step (mlp_small.hip) pays two kernel boundaries (~1.9 us each on this chip) plus
-// two store -> load round trips through L2 between the forward pass and the weight gradients.
-// Here everything after the hidden layer runs in ONE launch, which is possible without any
-// inter-workgroup synchronisation because the softmax gradient is cheap enough to recompute:
+// What bounds this step is not arithmetic but (a) kernel boundaries (~1.9 us each) and (b) dependent
+// memory hops: L2 is written back / invalidated at every kernel boundary, so the first touch of anything
+// the previous launch produced costs a trip to memory (~1 us), and an index -> row gather costs two.
+// The design therefore is: two launches, and no load in either of them depends on another load.
 //
-//   launch 1 (fwd):  H = relu(X[rows] W1 + b1), one 16x16 tile per 16-wave workgroup (split-K).
-//                    The finished tile is multiplied by its 16 rows of W2 right away and stored as a
-//                    partial-logit slab zpart[row][class][column tile]; b2 rides on tile 0.  The
-//                    launch also snapshots W2 and the step counters for launch 2.
+//   launch 1 (fwd):  H = relu(Xg W1 + b1), one 16x16 tile per 16-wave workgroup (split-K).  Xg holds the
+//                    batch rows already gathered (by the previous step's launch 2).  The finished tile is
+//                    multiplied by its 16 rows of W2 right away and stored as a partial-logit slab
+//                    zpart[class][row][column tile]; b2 rides on tile 0.  The launch also snapshots W2 and
+//                    the step counters for launch 2.
 //   launch 2 (bwd):  - R/16 "stat" workgroups: logits = sum of slabs, loss / accuracy partials of their
 //                      16 rows, written straight into the step's wide log record (summed by the host).
-//                    - ceil(tiles/4) "train" workgroups, one weight-gradient tile per wave.  Every
-//                      workgroup first recomputes dz2 for the whole batch from the slabs (7 rows of
-//                      math per lane) into LDS; a dW1 wave then rebuilds its dz1 tile with 3-4 MFMAs
-//                      per 16 batch rows, and because the MFMA result layout (reg r = row 4g+r,
-//                      col = lane&15) is exactly the B-operand layout of the next MFMA when batch
-//                      row 16rb+4g+j is fed to instruction j, dz1 never leaves registers.
-//                    - one tail workgroup: counters, next batch rows.
+//                    - "train" workgroups, one weight-gradient tile per wave.  Every workgroup first
+//                      recomputes dz2 of the whole batch into LDS: one batch row per lane, the classes in
+//                      registers (no cross-lane reductions).  A dW1 wave then rebuilds its dz1 tile with
+//                      3-4 MFMAs per 16 batch rows; the MFMA result layout (reg r = row 4g+r,
+//                      col = lane&15) is exactly the B-operand layout of the next MFMA when batch row
+//                      16rb+4g+j is fed to instruction j, so dz1 never leaves registers.
+//                    - "tail" workgroups: counters, and the NEXT step's batch: row indices, gathered
+//                      image rows and label rows, off the critical path of the train workgroups.
 //   Launch 2 updates W2/b2 while other workgroups still need W2 for dz1: they read the snapshot.
+//   Per-step buffers (Xg, labg, ridx) rotate with period 3: launch 2 of step s reads slot s (batch) and
+//   s-1 (accuracy-only rows = the previous batch) while its tail workgroups fill slot s+1.
 #include "dtf_device.h"
 
 // Diagnostic build only (-DDTF_STAMPS): per-workgroup timestamps of the 100 MHz constant clock.
@@ -36,12 +40,22 @@ extern "C" __attribute__((visibility("default"))) int dtf_set_stamp_buffer_mlp2(
 #define M2_STAMP(slot, wg) do { } while (0)
 #endif
 
-__device__ __forceinline__ void bld4i(rsrc_t r, unsigned off, int (&v)[4]) {
-  auto t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-  v[0] = (int)t[0]; v[1] = (int)t[1]; v[2] = (int)t[2]; v[3] = (int)t[3];
+// raw buffer loads with a wave-uniform (scalar) offset added to the per-lane one: the per-load address
+// arithmetic then runs on the scalar unit instead of costing several VALU operations per load
+__device__ __forceinline__ float bld_s(rsrc_t r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
-// position of class c inside a 16-float LDS row: a 16-byte read at 4*g returns classes g, 4+g, 8+g, 12+g
-__device__ __forceinline__ int dz_slot(int c) { return 4 * (c & 3) + (c >> 2); }
+__device__ __forceinline__ void bld4_s(rsrc_t r, unsigned voff, unsigned soff, float (&v)[4]) {
+  auto t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  v[0] = __uint_as_float(t[0]); v[1] = __uint_as_float(t[1]); v[2] = __uint_as_float(t[2]); v[3] = __uint_as_float(t[3]);
+}
+
+#define MLP2_ROWS 128               // rows per slot of Xg / labg (batch rows beyond B stay zero)
+#define MLP2_LABG_ROWS 128          // batch rows per class in a labg slot
+#define MLP2_LABG_SLOT (16 * MLP2_LABG_ROWS)
+
+__device__ __forceinline__ int mlp2_prev_slot(int q) { return q == 0 ? 2 : q - 1; }
+__device__ __forceinline__ int mlp2_next_slot(int q) { return q == 2 ? 0 : q + 1; }
 
 // ------------------------------------------------------------------------------------------
 // launch 1
@@ -53,11 +67,15 @@ __global__ __launch_bounds__(1024) void mlp2_fwd_kernel(DtfMlp2Args p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, g = lane >> 4;
   const int nt = blockIdx.x, n0 = nt * 16, m0 = blockIdx.y * 16;
-  const int Hd = p.Hd, C = p.C;
-  const rsrc_t ra = make_rsrc(p.X, p.x_bytes), rb = make_rsrc(p.W1, (unsigned)p.In * (unsigned)Hd * 4u);
+  const int Hd = p.Hd, C = p.C, B = p.B;
+  const int Rp = ((p.R + 15) >> 4) << 4;
+  const unsigned slot_bytes = (unsigned)MLP2_ROWS * (unsigned)p.In * 4u;
+  const rsrc_t ra = make_rsrc(p.Xg, 3u * slot_bytes), rb = make_rsrc(p.W1, (unsigned)p.In * (unsigned)Hd * 4u);
+  // logical row r: [0,B) = this step's batch (slot q), [B,R) = the previous batch (slot q-1)
   const int arow = m0 + fr;
-  const int asrc = p.ridx[arow];          // the table is padded to whole row blocks
-  const unsigned a_row_off = arow < p.R ? (unsigned)asrc * (unsigned)p.ldx * 4u : kOOB;
+  const int aslot = arow < B ? p.q : mlp2_prev_slot(p.q);
+  const int asrc = arow < B ? arow : arow - B;
+  const unsigned a_row_off = arow < p.R ? (unsigned)aslot * slot_bytes + (unsigned)asrc * (unsigned)p.In * 4u : kOOB;
   const int bcol = n0 + fr;
   const unsigned b_lane_off = bcol < Hd ? (unsigned)bcol * 4u : kOOB;
 
@@ -83,15 +101,6 @@ __global__ __launch_bounds__(1024) void mlp2_fwd_kernel(DtfMlp2Args p) {
   if (blockIdx.y == 0 && (int)threadIdx.x < 16 * C) {
     const int idx = n0 * C + (int)threadIdx.x;
     if (idx < Hd * C) { snap_idx = idx; snapv = p.W2[idx]; }
-  }
-  // the last column tile of every row block also gathers the label rows of its 16 batch rows
-  float labv = 0.f;
-  const bool lab_wg = blockIdx.x == gridDim.x - 1 && threadIdx.x < 256;
-  if (lab_wg) {
-    const int row = m0 + ((int)threadIdx.x >> 4), c = (int)threadIdx.x & 15;
-    const bool ok = row < p.R && c < C;
-    const float v = p.labels[ok ? (size_t)p.ridx[row] * C + c : 0];
-    labv = ok ? v : 0.f;
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) p.ctr_snap[threadIdx.x] = p.tail.state[threadIdx.x];
 
@@ -141,77 +150,69 @@ __global__ __launch_bounds__(1024) void mlp2_fwd_kernel(DtfMlp2Args p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 4 * g + r;
-      if (row < p.R) p.zpart[((size_t)row * 16 + fr) * 8 + nt] = (z0[r] + z1[r]) + b2v;
+      if (row < p.R) p.zpart[((size_t)fr * Rp + row) * 8 + nt] = (z0[r] + z1[r]) + b2v;
     }
   }
   if (snap_idx >= 0) p.W2s[snap_idx] = snapv;
-  if (lab_wg) p.labg[(size_t)m0 * 16 + threadIdx.x] = labv;
   M2_STAMP(4, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
 // launch 2
 // ------------------------------------------------------------------------------------------
-// Softmax / loss math of one row spread over 16 lanes (lane & 15 = class).  Returns d loss / d logit.
-template <bool FULL>
-__device__ __forceinline__ float mlp2_row_math(float zsum, float lab, bool cls_ok, int fr, int loss_mode, float inv_b,
-                                               float& loss, int& hit) {
+// Softmax / loss math of one row spread over 16 lanes (lane & 15 = class): the stat workgroups.
+__device__ __forceinline__ void mlp2_row_stats(float zsum, float lab, bool cls_ok, int fr, int loss_mode, float& loss,
+                                               int& hit) {
   const float NEG_INF = -__builtin_huge_valf();
   const float z = cls_ok ? zsum : NEG_INF;
   const float zmax = row16_max(z);
   const float e1 = __expf(z - zmax);                 // 0 on the padding lanes
   const float s1 = row16_sum(e1);
-  const float y = e1 * __builtin_amdgcn_rcpf(s1);
-  float logp, dz;
+  float logp;
   if (loss_mode == 0) {
     // softmax applied a second time on the probabilities (the reference feeds y as "logits")
+    const float y = e1 * __builtin_amdgcn_rcpf(s1);
     const float ymax = row16_max(cls_ok ? y : NEG_INF);
     const float e2 = cls_ok ? __expf(y - ymax) : 0.f;
     const float s2 = row16_sum(e2);
-    const float pp = e2 * __builtin_amdgcn_rcpf(s2);
-    const float dy = (pp - lab) * inv_b;
-    const float dot = row16_sum(dy * y);
-    dz = (dy - dot) * y;
-    if (FULL) logp = (y - ymax) - __logf(s2);
+    logp = (y - ymax) - __logf(s2);
   } else {
-    dz = (y - lab) * inv_b;
-    if (FULL) logp = (z - zmax) - __logf(s1);
+    logp = (z - zmax) - __logf(s1);
   }
-  if (FULL) {
-    loss = -row16_sum(cls_ok ? lab * logp : 0.f);
-    // argmax with lowest-index tie break (tf.argmax, distributed.py:83)
-    const int am_y = row16_min((cls_ok && z == zmax) ? fr : 16);
-    const float labmax = row16_max(cls_ok ? lab : NEG_INF);
-    const int am_l = row16_min((cls_ok && lab == labmax) ? fr : 16);
-    hit = am_y == am_l ? 1 : 0;
-  }
-  return dz;
+  loss = -row16_sum(cls_ok ? lab * logp : 0.f);
+  // argmax with lowest-index tie break (tf.argmax, distributed.py:83)
+  const int am_y = row16_min((cls_ok && z == zmax) ? fr : 16);
+  const float labmax = row16_max(cls_ok ? lab : NEG_INF);
+  const int am_l = row16_min((cls_ok && lab == labmax) ? fr : 16);
+  hit = am_y == am_l ? 1 : 0;
 }
 
 __device__ __forceinline__ float sum8(const float (&a)[4], const float (&b)[4]) {
   return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
 }
 
-__device__ __forceinline__ void mlp2_stat_block(const DtfMlp2Args& p, int rb, unsigned zbytes) {
+__device__ __forceinline__ void mlp2_stat_block(const DtfMlp2Args& p, int rb, int Rp, unsigned zbytes) {
   __shared__ float part_loss[4];
   __shared__ int part_cnt[4][2];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, g = lane >> 4;
-  const int C = p.C;
-  const bool cls_ok = fr < C;
+  const bool cls_ok = fr < p.C;
   const int row = 16 * rb + 4 * g + wave;
   const bool row_ok = row < p.R, train_row = row < p.B;
   M2_STAMP(0, blockIdx.x);
-  const rsrc_t rz = make_rsrc(p.zpart, zbytes), rl = make_rsrc(p.labg, zbytes >> 3);
+  const rsrc_t rz = make_rsrc(p.zpart, zbytes), rl = make_rsrc(p.labg, 3u * MLP2_LABG_SLOT * 4u);
   float za[4], zb[4];
-  bld4(rz, (unsigned)(row * 16 + fr) * 32u, za);
-  bld4(rz, (unsigned)(row * 16 + fr) * 32u + 16u, zb);
-  const float lab = bld(rl, (unsigned)(row * 16 + fr) * 4u);     // 0 on padding rows / classes
+  const unsigned zoff = (unsigned)(fr * Rp + row) * 32u;
+  bld4(rz, zoff, za);
+  bld4(rz, zoff + 16u, zb);
+  const int lslot = train_row ? p.q : mlp2_prev_slot(p.q);
+  const int lrow = train_row ? row : row - p.B;
+  const float lab = bld(rl, row_ok ? (unsigned)(lslot * MLP2_LABG_SLOT + fr * MLP2_LABG_ROWS + lrow) * 4u : kOOB);
   const int ls = p.ctr_snap[1];
   float loss = 0.f;
   int hit = 0;
-  (void)mlp2_row_math<true>(sum8(za, zb), lab, cls_ok, fr, p.loss_mode, p.inv_b, loss, hit);
+  mlp2_row_stats(sum8(za, zb), lab, cls_ok, fr, p.loss_mode, loss, hit);
   float loss_acc = 0.f;
   int correct_acc = 0, post_acc = 0;
   if (fr == 0 && row_ok) {
@@ -239,37 +240,121 @@ __device__ __forceinline__ void mlp2_stat_block(const DtfMlp2Args& p, int rb, un
   M2_STAMP(6, blockIdx.x);
 }
 
-__device__ __forceinline__ void mlp2_tail_block(const DtfMlp2Args& p) {
+// Tail workgroup tb: counters (tb == 0) and rows [8*tb, 8*tb+8) of the next step's batch: 32 threads per row
+// copy the image row into the next Xg slot, the label row into the next labg slot, the index into ridx.
+__device__ __forceinline__ void mlp2_tail_block(const DtfMlp2Args& p, int tb) {
   const DtfTailArgs& t = p.tail;
   const int tid = threadIdx.x;
   M2_STAMP(0, blockIdx.x);
-  const int gs = t.state[0], ls = t.state[1];
-  __syncthreads();   // every thread holds the counters before thread 0 advances them
-  if (tid == 0) {
+  const int gs = p.ctr_snap[0], ls = p.ctr_snap[1];   // taken by launch 1: nobody reads state[] while it is advanced
+  const int B = p.B, C = p.C;
+  const int sub = tid >> 5, l = tid & 31;
+  const int i = 8 * tb + sub;
+  const int qn = mlp2_next_slot(p.q);
+  if (tb == 0 && tid == 0) {
     int* rec = p.wlog + (size_t)DTF_WLOG_INTS * (ls % p.log_cap);
     rec[0] = gs;       // value of global_step before this step's increment
     rec[1] = ls;
     t.state[0] = gs + t.gs_inc;
     t.state[1] = ls + 1;
   }
-  if (t.ridx_next) {
-    const int next = ls + 1;
-    for (int i = tid; i < t.B; i += 256) {
-      const long long q = (long long)next * t.B + i;
-      const long long epoch = q / t.n_train;
-      const int pos = (int)(q - epoch * t.n_train);
-      const int row = t.perm ? t.perm[(size_t)(epoch & 1) * t.n_train + pos] : pos;
-      t.ridx_next[t.B + i] = t.ridx_cur[i];   // the batch just trained on becomes the accuracy-only rows
-      t.ridx_next[i] = row;
+  if (i >= B) return;
+  const long long pos64 = (long long)(ls + 1) * B + i;
+  const long long epoch = pos64 / t.n_train;
+  const int pos = (int)(pos64 - epoch * t.n_train);
+  const int row = t.perm ? t.perm[(size_t)(epoch & 1) * t.n_train + pos] : pos;
+  const f32x4* src = reinterpret_cast<const f32x4*>(p.X + (size_t)row * p.ldx);
+  f32x4* dst = reinterpret_cast<f32x4*>(p.Xg + ((size_t)qn * MLP2_ROWS + i) * p.In);
+  const int n4 = p.In >> 2;
+  for (int base = 0; base < n4; base += 32 * 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = base + 32 * u + l;
+      v[u] = src[k < n4 ? k : 0];
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = base + 32 * u + l;
+      if (k < n4) dst[k] = v[u];
+    }
+  }
+  if (l < 16) {
+    const float v = p.labels[(size_t)row * C + (l < C ? l : 0)];
+    p.labg[qn * MLP2_LABG_SLOT + l * MLP2_LABG_ROWS + i] = l < C ? v : 0.f;
+  }
+  if (l == 16) {
+    int* rn = p.ridx + (size_t)qn * p.ridx_len;
+    rn[i] = row;
+    rn[B + i] = p.ridx[(size_t)p.q * p.ridx_len + i];   // the batch just trained on becomes the accuracy-only rows
   }
   M2_STAMP(6, blockIdx.x);
 }
 
+// Softmax gradient of batch row `row` (one row per lane, classes in registers), written to LDS in the
+// permuted class order the dz1 MFMAs read: a 16-byte read at 4*g returns classes g, 4+g, 8+g, 12+g.
+template <int CP>
+__device__ __forceinline__ void mlp2_dz2_row(const float (&z)[CP], const float (&lab)[CP], int C, bool row_ok, int loss_mode,
+                                             float inv_b, float* dz_row) {
+  const float NEG_INF = -__builtin_huge_valf();
+  float zmax = NEG_INF;
+#pragma unroll
+  for (int c = 0; c < CP; ++c) zmax = fmaxf(zmax, c < C ? z[c] : NEG_INF);
+  float e1[CP], s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    e1[c] = c < C ? __expf(z[c] - zmax) : 0.f;
+    s1 += e1[c];
+  }
+  const float inv1 = __builtin_amdgcn_rcpf(s1);
+  float dz[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) dz[c] = 0.f;
+  if (loss_mode == 0) {
+    // softmax applied a second time on the probabilities (the reference feeds y as "logits")
+    float y[CP], ymax = NEG_INF;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      y[c] = e1[c] * inv1;
+      ymax = fmaxf(ymax, c < C ? y[c] : NEG_INF);
+    }
+    float e2[CP], s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      e2[c] = c < C ? __expf(y[c] - ymax) : 0.f;
+      s2 += e2[c];
+    }
+    const float inv2 = __builtin_amdgcn_rcpf(s2);
+    float dy[CP], dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      dy[c] = (e2[c] * inv2 - lab[c]) * inv_b;
+      dot += dy[c] * y[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) dz[c] = (dy[c] - dot) * y[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < CP; ++c) dz[c] = (e1[c] * inv1 - lab[c]) * inv_b;
+  }
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = q4 + 4 * j;
+      v[j] = (row_ok && c < C) ? dz[c] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dz_row + 4 * q4) = v;
+  }
+}
+__device__ __forceinline__ int dz_slot(int c) { return 4 * (c & 3) + (c >> 2); }
+
 // One weight-gradient tile per wave.  IS2 = false: tiles of dW1 (inputs x hidden), dz1 rebuilt in registers;
 // IS2 = true: tiles of dW2 (hidden x classes).  `tile0` is the first tile of this workgroup within its kind.
 template <int NJ, int NRB, bool IS2>
-__device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0, unsigned zbytes, float* dzs) {
+__device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0, int Rp, unsigned zbytes, float* dzs) {
+  constexpr int CP = 4 * NJ;                        // classes padded to whole MFMA k-steps
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -284,39 +369,49 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
   const int m0 = mt * 16, n0 = nt * 16;
   const int Mo = IS2 ? Hd : p.In, N = IS2 ? C : Hd;
   const bool am_ok = has_tile && m0 + fr < Mo, bn_ok = has_tile && n0 + fr < N;
-  const bool cls_ok = fr < C;
-  const unsigned h_bytes = (unsigned)(((size_t)(p.R - 1) * p.ldh + Hd) * 4u);
+  const unsigned h_bytes = (unsigned)(((size_t)(MLP2_ROWS - 1) * p.ldh + Hd) * 4u);   // H holds >= MLP2_ROWS rows
   M2_STAMP(0, blockIdx.x);
 
-  // ---- operands of the softmax-gradient pass: this wave owns rows 16*rb + 4*g + wave ----
-  const rsrc_t rz = make_rsrc(p.zpart, zbytes), rl = make_rsrc(p.labg, zbytes >> 3);
-  float za[NRB][4], zb[NRB][4], lab[NRB];
+  // ---- operands of the softmax-gradient pass: lane tid < 16*NRB owns batch row tid ----
+  const bool p1_wave = wave * 64 < 16 * NRB;        // wave-uniform
+  float lab[CP], za[CP][4], zb[CP][4];
+  if (p1_wave) {
+    // no guards: slab entries of padding classes / rows are zero, and so are label rows beyond the batch
+    const rsrc_t rz = make_rsrc(p.zpart, zbytes), rl = make_rsrc(p.labg, 3u * MLP2_LABG_SLOT * 4u);
+    const unsigned zv = tid < Rp ? (unsigned)tid * 32u : kOOB, lv = (unsigned)tid * 4u;
 #pragma unroll
-  for (int rb = 0; rb < NRB; ++rb) {
-    const unsigned e = (unsigned)((16 * rb + 4 * g + wave) * 16 + fr);   // past the buffers: reads 0
-    bld4(rz, e * 32u, za[rb]);
-    bld4(rz, e * 32u + 16u, zb[rb]);
-    lab[rb] = bld(rl, e * 4u);
+    for (int c = 0; c < CP; ++c) {
+      bld4_s(rz, zv, (unsigned)(c * Rp) * 32u, za[c]);
+      bld4_s(rz, zv + 16u, (unsigned)(c * Rp) * 32u, zb[c]);
+      lab[c] = bld_s(rl, lv, (unsigned)(p.q * MLP2_LABG_SLOT + c * MLP2_LABG_ROWS) * 4u);
+    }
   }
-  // ---- operands of the tile, requested now so that they arrive during the softmax pass ----
+  // ---- operands of the tile, requested before anything waits on the loads above ----
   float* const Wt = IS2 ? p.W2 : p.W1;
   float* const bt = IS2 ? p.b2 : p.b1;
   const rsrc_t rwt = make_rsrc(Wt, (unsigned)Mo * (unsigned)N * 4u), rbt = make_rsrc(bt, (unsigned)N * 4u);
   const rsrc_t rh = make_rsrc(p.H, h_bytes);
-  int xr[NRB][4];
   float av[NRB][4], hm[NRB][4], wb[4] = {0.f, 0.f, 0.f, 0.f}, wold[4] = {0.f, 0.f, 0.f, 0.f}, bold = 0.f;
-  if (!IS2) {
-    const rsrc_t rri = make_rsrc(p.ridx, (unsigned)p.ridx_len * 4u);
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) bld4i(rri, (unsigned)(16 * rb + 4 * g) * 4u, xr[rb]);
-    const rsrc_t rw = make_rsrc(p.W2s, (unsigned)Hd * (unsigned)C * 4u);
+  {
+    // Row 16*rb + 4*g + j of the A operand feeds MFMA j of row block rb.  Rows beyond the batch are zero
+    // in Xg (padded slots) and harmless in H (their dz2 is zero), so only the column guard remains.
+    const unsigned slot_bytes = (unsigned)MLP2_ROWS * (unsigned)p.In * 4u;
+    const rsrc_t ra = IS2 ? rh : make_rsrc(p.Xg + (size_t)p.q * MLP2_ROWS * p.In, slot_bytes);
+    const unsigned lda4 = (unsigned)(IS2 ? p.ldh : p.In) * 4u;
+    const unsigned av_base = am_ok ? (unsigned)(4 * g) * lda4 + (unsigned)(m0 + fr) * 4u : kOOB;
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * rb + 4 * g + r;
-        hm[rb][r] = bld(rh, (bn_ok && row < B) ? ((unsigned)row * (unsigned)p.ldh + (unsigned)(n0 + fr)) * 4u : kOOB);
-      }
+      for (int j = 0; j < 4; ++j) av[rb][j] = bld_s(ra, av_base, (unsigned)(16 * rb + j) * lda4);
+  }
+  if (!IS2) {
+    const rsrc_t rw = make_rsrc(p.W2s, (unsigned)Hd * (unsigned)C * 4u);
+    const unsigned ldh4 = (unsigned)p.ldh * 4u;
+    const unsigned hm_base = bn_ok ? (unsigned)(4 * g) * ldh4 + (unsigned)(n0 + fr) * 4u : kOOB;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hm[rb][r] = bld_s(rh, hm_base, (unsigned)(16 * rb + r) * ldh4);
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
       wb[j] = bld(rw, (bn_ok && 4 * j + g < C) ? ((unsigned)(n0 + fr) * (unsigned)C + (unsigned)(4 * j + g)) * 4u : kOOB);
@@ -329,30 +424,14 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     }
     bold = bld(rbt, (mt == 0 && g == 0 && bn_ok) ? (unsigned)(n0 + fr) * 4u : kOOB);
   }
-  {
-    const rsrc_t ra = IS2 ? rh : make_rsrc(p.X, p.x_bytes);
-    const unsigned lda4 = (unsigned)(IS2 ? p.ldh : p.ldx) * 4u;
-    const unsigned a_lane = (unsigned)(m0 + fr) * 4u;
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = 16 * rb + 4 * g + j;                      // batch row fed to MFMA j of row block rb
-        const unsigned src = IS2 ? (unsigned)k : (unsigned)xr[rb][j];
-        av[rb][j] = bld(ra, (am_ok && k < B) ? src * lda4 + a_lane : kOOB);
-      }
-  }
   M2_STAMP(1, blockIdx.x);
 
-  // ---- softmax gradient of the whole batch into LDS (recomputed by every workgroup); the row blocks are
-  //      independent dependency chains, left unrolled so that they interleave ----
+  // ---- softmax gradient of the whole batch into LDS (recomputed by every workgroup) ----
+  if (p1_wave) {
+    float z[CP];
 #pragma unroll
-  for (int rb = 0; rb < NRB; ++rb) {
-    const int row = 16 * rb + 4 * g + wave;
-    float loss;
-    int hit;
-    const float dz = mlp2_row_math<false>(sum8(za[rb], zb[rb]), lab[rb], cls_ok, fr, p.loss_mode, p.inv_b, loss, hit);
-    dzs[row * 20 + dz_slot(fr)] = (row < B && cls_ok) ? dz : 0.f;
+    for (int c = 0; c < CP; ++c) z[c] = sum8(za[c], zb[c]);
+    mlp2_dz2_row<CP>(z, lab, C, tid < B, p.loss_mode, p.inv_b, dzs + tid * 20);
   }
   M2_STAMP(3, blockIdx.x);
   __syncthreads();
@@ -416,37 +495,35 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
   M2_STAMP(6, blockIdx.x);
 }
 
-// workgroups of launch 2: [0, R16) stat | nb1 blocks of dW1 tiles | nb2 blocks of dW2 tiles | 1 tail
+// workgroups of launch 2: [0, R16) stat | nb1 blocks of dW1 tiles | nb2 blocks of dW2 tiles | ceil(B/8) tail
 template <int NJ, int NRB>
 __global__ __launch_bounds__(256) void mlp2_bwd_kernel(DtfMlp2Args p) {
   __shared__ float dzs[128 * 20];
-  const int R16 = (p.R + 15) >> 4;
+  const int R16 = (p.R + 15) >> 4, Rp = R16 << 4;
   const int NT = (p.Hd + 15) >> 4;
   const int nb1 = (((p.In + 15) >> 4) * NT + 3) >> 2, nb2 = (NT + 3) >> 2;
-  const unsigned zbytes = (unsigned)R16 * 16u * 16u * 8u * 4u;
+  const unsigned zbytes = 16u * (unsigned)Rp * 8u * 4u;
   const int b = blockIdx.x;
-  if (b < R16) mlp2_stat_block(p, b, zbytes);
-  else if (b < R16 + nb1) mlp2_train_block<NJ, NRB, false>(p, (b - R16) * 4, zbytes, dzs);
-  else if (b < R16 + nb1 + nb2) mlp2_train_block<NJ, NRB, true>(p, (b - R16 - nb1) * 4, zbytes, dzs);
-  else mlp2_tail_block(p);
+  if (b < R16) mlp2_stat_block(p, b, Rp, zbytes);
+  else if (b < R16 + nb1) mlp2_train_block<NJ, NRB, false>(p, (b - R16) * 4, Rp, zbytes, dzs);
+  else if (b < R16 + nb1 + nb2) mlp2_train_block<NJ, NRB, true>(p, (b - R16 - nb1) * 4, Rp, zbytes, dzs);
+  else mlp2_tail_block(p, b - R16 - nb1 - nb2);
 }
 
 static int mlp2_validate(const DtfMlp2Args* a) {
-  if (!a || !a->X || !a->ridx || !a->labels || !a->H || !a->zpart || !a->labg || !a->W2s || !a->ctr_snap || !a->wlog) return DTF_ERR_ARG;
+  if (!a || !a->X || !a->labels || !a->Xg || !a->labg || !a->ridx || !a->H || !a->zpart || !a->W2s || !a->ctr_snap || !a->wlog)
+    return DTF_ERR_ARG;
   if (!a->W1 || !a->b1 || !a->W2 || !a->b2 || !a->tail.state) return DTF_ERR_ARG;
   if (a->mode == 0 ? (!a->dW1 || !a->db1 || !a->dW2 || !a->db2) : a->mode != 1) return DTF_ERR_ARG;
-  if (a->In <= 0 || a->Hd <= 0 || a->Hd > 128 || a->C <= 0 || a->C > 16 || a->B <= 0 || a->B > 128) return DTF_ERR_SHAPE;
+  if (a->In <= 0 || a->Hd <= 0 || a->Hd > 128 || a->C <= 0 || a->C > 16 || a->B <= 0 || a->B > MLP2_LABG_ROWS) return DTF_ERR_SHAPE;
   if (a->R != a->B && a->R != 2 * a->B) return DTF_ERR_SHAPE;
+  if (a->q < 0 || a->q > 2) return DTF_ERR_ARG;
   if (a->ldx < a->In || a->ldh < a->Hd || a->log_cap <= 0) return DTF_ERR_SHAPE;
   if ((a->In & 3) || (a->ldx & 3)) return DTF_ERR_SHAPE;
-  if (!dtf_aligned16(a->X) || !dtf_aligned16(a->ridx) || !dtf_aligned16(a->zpart)) return DTF_ERR_ALIGN;
-  // every row index up to the padded row count is read unguarded
-  if ((a->ridx_len & 15) || a->ridx_len < 16 * dtf_cdiv(a->R, 16) || a->ridx_len < 128) return DTF_ERR_SHAPE;
-  if (a->x_bytes == 0 || a->x_bytes >= 0xFFFFFFF0u) return DTF_ERR_SHAPE;
-  if (a->tail.enable) {
-    if (a->tail.B != a->B || a->tail.n_train <= 0 || a->tail.log_cap != a->log_cap) return DTF_ERR_SHAPE;
-    if (a->tail.ridx_next && (!a->tail.ridx_cur || a->tail.ridx_next == a->tail.ridx_cur)) return DTF_ERR_SHAPE;
-  }
+  if (!dtf_aligned16(a->X) || !dtf_aligned16(a->Xg) || !dtf_aligned16(a->zpart)) return DTF_ERR_ALIGN;
+  if (a->ridx_len < 2 * a->B) return DTF_ERR_SHAPE;
+  if ((uint64_t)3 * MLP2_ROWS * a->In * 4u >= 0xFFFFFFF0u || a->h_rows < MLP2_ROWS || a->h_rows < a->R) return DTF_ERR_SHAPE;
+  if (a->tail.n_train <= 0 || !a->tail.enable) return DTF_ERR_SHAPE;
   return DTF_OK;
 }
 
@@ -469,9 +546,8 @@ static void mlp2_launch_bwd(const DtfMlp2Args& a, int nblk, hipStream_t s) {
 DTF_EXPORT int dtf_mlp2_bwd(const DtfMlp2Args* a, hipStream_t s) {
   const int rc = mlp2_validate(a);
   if (rc != DTF_OK) return rc;
-  if (!a->tail.enable) return DTF_ERR_ARG;
   const int NT = dtf_cdiv(a->Hd, 16);
-  const int nblk = dtf_cdiv(a->R, 16) + dtf_cdiv(dtf_cdiv(a->In, 16) * NT, 4) + dtf_cdiv(NT, 4) + 1;
+  const int nblk = dtf_cdiv(a->R, 16) + dtf_cdiv(dtf_cdiv(a->In, 16) * NT, 4) + dtf_cdiv(NT, 4) + dtf_cdiv(a->B, 8);
   if (a->C <= 12) mlp2_launch_bwd<3>(*a, nblk, s);
   else mlp2_launch_bwd<4>(*a, nblk, s);
   return dtf_check_launch();

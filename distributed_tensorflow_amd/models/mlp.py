@@ -69,7 +69,7 @@ class MLPProgram:
         self.use_graphs = self.is_cuda if use_graphs is None else (use_graphs and self.is_cuda)
         dev, f32, i32 = self.device, torch.float32, torch.int32
         self.names = hidden_names(len(self.hidden))
-        self.hact = [torch.zeros((self.R, h), dtype=f32, device=dev) for h in self.hidden]
+        self.hact = [torch.zeros((max(self.R, 128), h), dtype=f32, device=dev) for h in self.hidden]
         self.dz = [torch.zeros((batch, h), dtype=f32, device=dev) for h in self.hidden]
         self.dz2 = torch.zeros((batch, 16), dtype=f32, device=dev)
         self.nblk = (self.R + 15) // 16
@@ -78,17 +78,21 @@ class MLPProgram:
         self.post_part = torch.zeros(self.nblk, dtype=i32, device=dev)
         self.log_cap = log_capacity
         self.log = torch.zeros((log_capacity, 4), dtype=i32, device=dev)
-        # row index tables (one per step parity), padded to whole 16-row blocks: kernels read the padding unguarded
-        self.ridx = torch.zeros((2, max(128, (2 * batch + 15) // 16 * 16)), dtype=i32, device=dev)
         # Two-launch step (csrc/kernels/mlp2_fused.hip) for the reference shape; DTF_FUSED_STEP=0 selects the
         # general three-launch sequence for A/B measurements.
         in_dim = state.var(f"{self.names[0]}_w").shape[0]
         self.fused2 = (self.is_cuda and type(self)._supports_mlp2 and os.environ.get("DTF_FUSED_STEP", "1") != "0"
                        and ops.mlp2_eligible(in_dim, self.hidden, classes, batch))
+        # Per-step buffers rotate over P slots (slot of a step = local step % P).  P = 2: the tail of step s
+        # writes the rows of step s+1 while step s is still being read.  The two-launch step also keeps the
+        # gathered batch of step s-1 (its accuracy-only rows), hence P = 3.
+        self.P = ops.MLP2_SLOTS if self.fused2 else 2
+        self.ridx = torch.zeros((self.P, max(128, (2 * batch + 15) // 16 * 16)), dtype=i32, device=dev)
         if self.fused2:
             r16 = (self.R + 15) // 16
-            self.zpart = torch.zeros(r16 * 16 * 16 * 8, dtype=f32, device=dev)
-            self.labg = torch.zeros(r16 * 16 * 16, dtype=f32, device=dev)
+            self.xg = torch.zeros((self.P, ops.MLP2_ROWS, in_dim), dtype=f32, device=dev)
+            self.labg = torch.zeros((self.P, 16, ops.MLP2_LABG_ROWS), dtype=f32, device=dev)
+            self.zpart = torch.zeros(16 * r16 * 16 * 8, dtype=f32, device=dev)
             self.w2_snap = torch.zeros(self.hidden[0] * classes, dtype=f32, device=dev)
             self.ctr_snap = torch.zeros(2, dtype=i32, device=dev)
             self.wlog = torch.zeros((log_capacity, ops._lib.WLOG_INTS), dtype=i32, device=dev)
@@ -98,7 +102,7 @@ class MLPProgram:
         self._schedules: Dict = {}
         self.schedule_tail_entries = []   # appended by the engine: the native update entry of each step
         self._eval_buf: Dict = {}
-        self._args = [self._build_args(0), self._build_args(1)] if self.is_cuda else None
+        self._args = [self._build_args(q) for q in range(self.P)] if self.is_cuda else None
         self._started = False
         # Called at the end of every step, inside the captured region: the engine's gradient
         # aggregation + shard update + parameter redistribution when the update is not fused.
@@ -107,8 +111,8 @@ class MLPProgram:
     # ------------------------------------------------------------------ argument packs (one per parity)
     def _tail(self, q: int):
         return ops.make_tail(self.state.state, self.log, self.loss_part, self.correct_part, self.post_part,
-                             ridx_cur=self.ridx[q], ridx_next=self.ridx[1 - q], perm=self.data.perm, batch=self.B,
-                             n_train=self.data.n, gs_inc=self.gs_inc)
+                             ridx_cur=self.ridx[q], ridx_next=self.ridx[(q + 1) % self.P], perm=self.data.perm,
+                             batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
 
     def _wgrad_items(self, q: int):
         st, items = self.state, []
@@ -130,14 +134,12 @@ class MLPProgram:
         wgrad = ops.build_wgrad_args(items, lr=st.lr if self.fused else None, tail=self._tail(q))
         out = {"head": head, "wgrad": wgrad, "items": items}
         if self.fused2:
-            tail = ops.make_tail(st.state, ridx_cur=self.ridx[q], ridx_next=self.ridx[1 - q], perm=self.data.perm,
-                                 batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
-            tail.log_cap = self.log_cap
+            tail = ops.make_tail(st.state, perm=self.data.perm, batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
             g = (lambda n: None) if self.fused else st.grad
             out["mlp2"] = ops.build_mlp2_args(
-                self.data.images, self.ridx[q], self.data.labels, self.hact[0], self.zpart, self.labg, self.w2_snap, self.ctr_snap,
-                st.var("hid_w"), st.var("hid_b"), st.var("sm_w"), st.var("sm_b"), self.wlog, self.B, self.R,
-                self.loss_mode, tail, lr=st.lr if self.fused else None, dw1=g("hid_w"), db1=g("hid_b"), dw2=g("sm_w"),
+                self.data.images, self.data.labels, self.xg, self.labg, self.ridx, self.hact[0], self.zpart, self.w2_snap,
+                self.ctr_snap, st.var("hid_w"), st.var("hid_b"), st.var("sm_w"), st.var("sm_b"), self.wlog, self.B, self.R,
+                self.loss_mode, q, tail, lr=st.lr if self.fused else None, dw1=g("hid_w"), db1=g("hid_b"), dw2=g("sm_w"),
                 db2=g("sm_b"))
         return out
 
@@ -155,12 +157,19 @@ class MLPProgram:
     def start(self) -> None:
         """Select the rows of the first batch (runs once, before the first step)."""
         self.steps_enqueued = self.state.local_step()
-        q = self.steps_enqueued & 1
+        q = self.steps_enqueued % self.P
         self.data.prepare(self.steps_enqueued, 0, self.B)
         if self.is_cuda:
             t = ops.make_tail(self.state.state, ridx_cur=None, ridx_next=self.ridx[q], perm=self.data.perm, batch=self.B,
                               n_train=self.data.n, gs_inc=0)
             ops.step_tail(t, init_only=True)
+            if self.fused2:
+                # the first step finds its batch (and, as its accuracy-only rows, the same batch) already gathered
+                rows = self.ridx[q][:self.B].long()
+                for slot in (q, (q - 1) % self.P):
+                    self.xg[slot][:self.B].copy_(self.data.images.index_select(0, rows))
+                    self.labg[slot].zero_()
+                    self.labg[slot][:self.C, :self.B].copy_(self.data.labels.index_select(0, rows).t())
         else:
             self._tail_cpu(q, init_only=True)
         self._started = True
@@ -196,7 +205,7 @@ class MLPProgram:
 
     def enqueue_step(self) -> None:
         """Enqueue one full training step on the current stream (no host synchronisation)."""
-        q = self.steps_enqueued & 1
+        q = self.steps_enqueued % self.P
         st, rows = self.state, self.ridx[q]
         if self.is_cuda:
             self._compute_schedule(q).run()
@@ -237,14 +246,14 @@ class MLPProgram:
             rows = self.data.perm[(epoch & 1), off].to(torch.int32)
         else:
             rows = off.to(torch.int32)
-        dst = self.ridx[q] if init_only else self.ridx[1 - q]
+        dst = self.ridx[q] if init_only else self.ridx[(q + 1) % self.P]
         prev = rows if init_only else self.ridx[q][:self.B].clone()
         dst[self.B:2 * self.B] = prev
         dst[:self.B] = rows
 
     # ------------------------------------------------------------------ multi-step execution
     def _graph_for(self, n: int):
-        key = (n, self.steps_enqueued & 1)
+        key = (n, self.steps_enqueued % self.P)
         g = self._graphs.get(key)
         if g is None:
             saved = self.steps_enqueued
@@ -321,7 +330,7 @@ class MLPProgram:
 
     def post_correct_of_last_step(self) -> int:
         """Post-update accuracy count of the most recent step (needs one extra forward)."""
-        q = self.steps_enqueued & 1
+        q = self.steps_enqueued % self.P
         rows = self.ridx[q][self.B:2 * self.B].contiguous()
         return self._count_correct(self.data.images, self.data.labels, rows=rows, n=self.B)
 

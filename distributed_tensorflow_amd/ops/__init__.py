@@ -267,48 +267,59 @@ def mlp2_eligible(in_dim, hidden, classes, batch) -> bool:
     return len(hidden) == 1 and hidden[0] <= 128 and classes <= 16 and batch <= 128 and in_dim % 4 == 0
 
 
-def build_mlp2_args(x, ridx, labels, hact, zpart, labg, w2_snap, ctr_snap, w1, b1, w2, b2, wlog, batch, rows_total, loss_mode,
-                    tail, lr=None, dw1=None, db1=None, dw2=None, db2=None):
-    """Argument pack of the two-launch step (K1-K11 of the reference graph in two kernels).  ``lr`` given:
-    SGD applied in the epilogue; otherwise the four gradients are stored."""
+MLP2_SLOTS = 3          # rotation period of the per-step buffers of the two-launch step
+MLP2_LABG_ROWS = 128
+MLP2_ROWS = 128          # rows per slot of the gathered-batch buffer
+
+
+def build_mlp2_args(x, labels, xg, labg, ridx, hact, zpart, w2_snap, ctr_snap, w1, b1, w2, b2, wlog, batch, rows_total,
+                    loss_mode, slot, tail, lr=None, dw1=None, db1=None, dw2=None, db2=None):
+    """Argument pack of the two-launch step (K1-K11 of the reference graph in two kernels) for buffer slot
+    ``slot``.  ``lr`` given: SGD applied in the epilogue; otherwise the four gradients are stored."""
     in_dim, hd = w1.shape
     c = w2.shape[1]
     if not mlp2_eligible(in_dim, [hd], c, batch):
         raise ValueError("mlp2: shape outside the fused step's range")
     if rows_total not in (batch, 2 * batch):
         raise ValueError("mlp2: rows_total must be B or 2B")
+    if not 0 <= slot < MLP2_SLOTS:
+        raise ValueError("mlp2: slot out of range")
     r16 = (rows_total + 15) // 16
     if x.shape[1] != in_dim or tuple(w2.shape) != (hd, c) or b1.numel() != hd or b2.numel() != c:
         raise ValueError("mlp2: parameter shapes do not chain")
     if labels.shape[1] != c or labels.shape[0] != x.shape[0]:
         raise ValueError("mlp2: labels do not match the dataset")
-    if hact.shape[0] < rows_total or hact.shape[1] != hd:
-        raise ValueError("mlp2: hact too small")
-    if zpart.numel() != r16 * 16 * 16 * 8 or labg.numel() != r16 * 16 * 16 or w2_snap.numel() < hd * c or ctr_snap.numel() < 2:
+    if hact.shape[0] < max(rows_total, MLP2_ROWS) or hact.shape[1] != hd:
+        raise ValueError("mlp2: hact needs max(rows_total, 128) rows")
+    if tuple(xg.shape) != (MLP2_SLOTS, MLP2_ROWS, in_dim) or tuple(labg.shape) != (MLP2_SLOTS, 16, MLP2_LABG_ROWS):
+        raise ValueError("mlp2: gathered-batch buffers have the wrong shape")
+    if zpart.numel() != 16 * r16 * 16 * 8 or w2_snap.numel() < hd * c or ctr_snap.numel() < 2:
         raise ValueError("mlp2: scratch buffers have the wrong size")
     if wlog.dim() != 2 or wlog.shape[1] != _lib.WLOG_INTS:
         raise ValueError("mlp2: wide log must be [capacity, 64]")
-    if ridx.numel() % 16 or ridx.numel() < max(128, r16 * 16):
-        raise ValueError("mlp2: row index table must be padded to >= 128 entries, a multiple of 16")
+    if ridx.dim() != 2 or ridx.shape[0] != MLP2_SLOTS or ridx.shape[1] < 2 * batch:
+        raise ValueError("mlp2: row index table must be [3, >= 2B]")
     fused = lr is not None
     if not fused and any(t is None for t in (dw1, db1, dw2, db2)):
         raise ValueError("mlp2: gradient outputs missing")
     for name, t, shp in (("dw1", dw1, (in_dim, hd)), ("dw2", dw2, (hd, c))):
         if t is not None and tuple(t.shape) != shp:
             raise ValueError(f"mlp2: {name} shape mismatch")
-    _same_device(x, ridx, labels, hact, zpart, labg, w2_snap, ctr_snap, w1, b1, w2, b2, wlog, dw1, db1, dw2, db2)
+    _same_device(x, ridx, labels, xg, labg, hact, zpart, w2_snap, ctr_snap, w1, b1, w2, b2, wlog, dw1, db1, dw2, db2)
     for name, t in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2), ("dw1", dw1), ("db1", db1), ("dw2", dw2), ("db2", db2),
-                    ("x", x), ("labels", labels), ("hact", hact), ("zpart", zpart), ("labg", labg), ("w2_snap", w2_snap)):
+                    ("x", x), ("labels", labels), ("xg", xg), ("labg", labg), ("hact", hact), ("zpart", zpart),
+                    ("w2_snap", w2_snap)):
         if t is not None:
             _f32c(t, name)
     for name, t in (("ridx", ridx), ("ctr_snap", ctr_snap), ("wlog", wlog)):
         _i32c(t, name)
-    return _lib.Mlp2Args(X=x.data_ptr(), ridx=ridx.data_ptr(), labels=labels.data_ptr(), H=hact.data_ptr(),
-                         zpart=zpart.data_ptr(), labg=labg.data_ptr(), W2s=w2_snap.data_ptr(), ctr_snap=ctr_snap.data_ptr(), W1=w1.data_ptr(),
-                         b1=b1.data_ptr(), W2=w2.data_ptr(), b2=b2.data_ptr(), dW1=_lib.ptr(dw1), db1=_lib.ptr(db1),
-                         dW2=_lib.ptr(dw2), db2=_lib.ptr(db2), wlog=wlog.data_ptr(), In=in_dim, Hd=hd, C=c, B=batch,
-                         R=rows_total, ldx=x.stride(0), ldh=hact.stride(0), ridx_len=ridx.numel(), loss_mode=loss_mode,
-                         mode=1 if fused else 0, log_cap=wlog.shape[0], lr=float(lr) if fused else 0.0, inv_b=1.0 / batch,
+    return _lib.Mlp2Args(X=x.data_ptr(), labels=labels.data_ptr(), Xg=xg.data_ptr(), labg=labg.data_ptr(),
+                         ridx=ridx.data_ptr(), H=hact.data_ptr(), zpart=zpart.data_ptr(), W2s=w2_snap.data_ptr(),
+                         ctr_snap=ctr_snap.data_ptr(), W1=w1.data_ptr(), b1=b1.data_ptr(), W2=w2.data_ptr(),
+                         b2=b2.data_ptr(), dW1=_lib.ptr(dw1), db1=_lib.ptr(db1), dW2=_lib.ptr(dw2), db2=_lib.ptr(db2),
+                         wlog=wlog.data_ptr(), In=in_dim, Hd=hd, C=c, B=batch, R=rows_total, ldx=x.stride(0),
+                         ldh=hact.stride(0), ridx_len=ridx.shape[1], h_rows=hact.shape[0], q=slot, loss_mode=loss_mode, mode=1 if fused else 0,
+                         log_cap=wlog.shape[0], lr=float(lr) if fused else 0.0, inv_b=1.0 / batch,
                          x_bytes=_lib.span_bytes(x), tail=tail)
 
 

@@ -53,5 +53,6 @@ for which in ("fwd", "bwd"):
             show("tiles", rel, slice(0, 91))
         else:
             show("stat", rel, slice(0, 13))
-            show("train", rel, slice(13, 13 + 88))
-            show("tail", rel, slice(101, 102))
+            show("dW1", rel, slice(13, 13 + 86))
+            show("dW2", rel, slice(99, 101))
+            show("tail", rel, slice(101, 114))
