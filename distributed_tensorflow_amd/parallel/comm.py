@@ -59,27 +59,44 @@ class Collectives:
         self.backend = backend_of(group)
         self._native_rs = self.backend == "nccl"
 
+    def _host(self, t: torch.Tensor) -> torch.Tensor:
+        """gloo rehearsals with GPU-resident state (several ranks sharing one GPU): the collective runs on
+        a host copy, so that gloo's own device-stream handling is not part of what is being rehearsed."""
+        return t.cpu() if (t.is_cuda and self.backend != "nccl") else t
+
     def reduce_scatter_sum(self, out_shard: torch.Tensor, full: torch.Tensor) -> None:
         if self._native_rs:
             dist.reduce_scatter_tensor(out_shard, full, op=dist.ReduceOp.SUM, group=self.group)
             return
-        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+        h = self._host(full)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
         n = out_shard.numel()
-        out_shard.copy_(full[self.rank * n:(self.rank + 1) * n])
+        out_shard.copy_(h[self.rank * n:(self.rank + 1) * n])
+        if h is not full:
+            full.copy_(h)
 
     def all_gather(self, full: torch.Tensor, shard: torch.Tensor) -> None:
         if self.backend == "nccl":
             dist.all_gather_into_tensor(full, shard, group=self.group)
             return
         n = shard.numel()
-        parts = [full[i * n:(i + 1) * n] for i in range(self.world)]
-        dist.all_gather(parts, shard.clone(), group=self.group)
+        h = self._host(full)
+        parts = [h[i * n:(i + 1) * n] for i in range(self.world)]
+        dist.all_gather(parts, self._host(shard).clone(), group=self.group)
+        if h is not full:
+            full.copy_(h)
 
     def all_reduce_sum(self, t: torch.Tensor) -> None:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        h = self._host(t)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        if h is not t:
+            t.copy_(h)
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> None:
-        dist.broadcast(t, src=src, group=self.group)
+        h = self._host(t)
+        dist.broadcast(h, src=src, group=self.group)
+        if h is not t:
+            t.copy_(h)
 
     def barrier(self) -> None:
         if self.backend == "nccl":

@@ -29,7 +29,7 @@ def _entry(rank, world, port, fn, args, q):
         q.put((rank, "err", traceback.format_exc()))
 
 
-def run_ranks(fn, world, *args, timeout=240):
+def run_ranks(fn, world, *args, timeout=100):
     """Run ``fn(rank, world, port, *args)`` in ``world`` processes; returns results by rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -37,10 +37,22 @@ def run_ranks(fn, world, *args, timeout=240):
     procs = [ctx.Process(target=_entry, args=(r, world, port, fn, args, q)) for r in range(world)]
     for p in procs:
         p.start()
+    import queue
+    import time
     results = {}
+    deadline = time.time() + timeout
     try:
-        for _ in range(world):
-            rank, status, payload = q.get(timeout=timeout)
+        while len(results) < world:
+            try:
+                rank, status, payload = q.get(timeout=1.0)
+            except queue.Empty:
+                # a rank that died without raising (signal, abort) leaves its peers blocked in a collective
+                dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0) and i not in results]
+                if dead:
+                    raise AssertionError(f"rank(s) exited without a result: {dead}")
+                if time.time() > deadline:
+                    raise AssertionError(f"ranks {sorted(set(range(world)) - set(results))} gave no result in {timeout}s")
+                continue
             if status != "ok":
                 raise AssertionError(f"rank {rank} failed:\n{payload}")
             results[rank] = payload
