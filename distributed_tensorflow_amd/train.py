@@ -26,6 +26,7 @@ from .cluster.spec import ClusterSpec, Role, split_hosts, validate_role
 from .data import mnist
 from .data.device_dataset import DeviceDataset
 from .models.mlp import MLPProgram, StepRecord, build_mlp_state
+from .utils import trace
 from .parallel.async_ps import AsyncParameterServerEngine
 from .parallel.sync_replicas import SyncReplicasEngine
 from .supervisor.supervisor import Supervisor
@@ -119,17 +120,20 @@ class TrainingLoop:
                     held.post_correct = prog.post_correct_of_last_step()
                     self._print_record(held)
                     held = None
-                self._validate()
+                with trace.annotate("validation"):
+                    self._validate()
             n = self._plan(gs_seen)
             first = self.local_step
-            self.engine.run(n, min(n, 64) if n >= 2 else 1)
+            with trace.annotate(f"launch {n} steps"):
+                self.engine.run(n, min(n, 64) if n >= 2 else 1)
             if self.stop_check is not None and self.stop_check():
                 n = prog.steps_enqueued - first  # the service ended training: keep what actually ran
                 done = True
                 if n <= 0:
                     break
             self.local_step += n
-            recs = prog.read_log(first, n)       # synchronises with the device
+            with trace.annotate("read step log"):
+                recs = prog.read_log(first, n)       # synchronises with the device
             if held is not None:
                 # the accuracy-only rows of this launch's first step re-scored the held step's batch
                 held.post_correct = self._post_of_previous(first)
@@ -148,7 +152,8 @@ class TrainingLoop:
                     break
             gs_seen = recs[-1].global_step + 1
             if self.sv is not None:
-                self.sv.maybe_checkpoint()
+                with trace.annotate("checkpoint check"):
+                    self.sv.maybe_checkpoint()
                 self.sv.report_step_rate(gs_seen)
         time_end = time.time()
         return time_end - time_begin
