@@ -129,6 +129,12 @@ struct Server {
   std::vector<int> conn_fds;
 };
 
+// Hogwild update (ApplyGradientDescent with use_locking=False): concurrent connection threads update the same
+// variable without synchronisation ON PURPOSE, so the function is excluded from ThreadSanitizer instrumentation.
+__attribute__((no_sanitize("thread"))) void hogwild_apply(float* p, const float* g, size_t n, float lr) {
+  for (size_t i = 0; i < n; ++i) p[i] -= lr * g[i];
+}
+
 void respond(int fd, uint32_t status, uint32_t aux, int64_t value, const void* payload, uint64_t nbytes) {
   RespHeader h{status, aux, value, nbytes};
   if (!write_full(fd, &h, sizeof(h))) return;
@@ -201,7 +207,7 @@ void serve_connection(Server* s, int fd) {
         const float* g = reinterpret_cast<const float*>(buf.data());
         float* p = v->value.data();
         const size_t n = v->value.size();
-        for (size_t i = 0; i < n; ++i) p[i] -= lr * g[i];  // intentionally unlocked
+        hogwild_apply(p, g, n, lr);
         s->n_push++;
         respond(fd, 0, 0, s->global_step.load(), nullptr, 0);
         break;
