@@ -106,7 +106,7 @@ def test_wgrad_grouped_fused_sgd_and_rows():
 
 
 @pytest.mark.parametrize("mode", [ops.LOSS_REFERENCE, ops.LOSS_STANDARD])
-@pytest.mark.parametrize("M,Mt,H,C", [(100, 100, 100, 10), (200, 100, 100, 10), (5000, 0, 100, 10), (37, 21, 52, 7),
+@pytest.mark.parametrize("M,Mt,H,C", [(100, 100, 100, 10), (200, 100, 100, 10), (5000, 0, 100, 10), (10000, 0, 100, 10), (37, 21, 52, 7),
                                       (64, 64, 4096, 10), (16, 16, 100, 16)])
 def test_head(mode, M, Mt, H, C):
     hact = torch.relu(_rand(M, H, seed=1))

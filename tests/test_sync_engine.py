@@ -52,9 +52,9 @@ def _check_equal_replicas(res):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("collective", ["all_reduce", "reduce_scatter"])
-def test_r_equals_n_is_the_mean_of_worker_gradients(collective):
-    world, steps = 2, 6
+@pytest.mark.parametrize("collective,world,steps", [("all_reduce", 2, 6), ("reduce_scatter", 2, 6), ("reduce_scatter", 4, 3),
+                                                    ("all_reduce", 8, 3)])
+def test_r_equals_n_is_the_mean_of_worker_gradients(collective, world, steps):
     res = run_ranks(_sync_worker, world, world, collective, steps, -1)
     _check_equal_replicas(res)
     params = oracle.init_params(16, seed=3)
