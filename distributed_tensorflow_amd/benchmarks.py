@@ -94,7 +94,7 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
         "metric": METRIC, "value": value, "unit": "examples/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype_name if wide else "fp32", "data": "synthetic MNIST-shape (resident in HBM), random-init weights",
-        "config": {"model": ("wide_mlp 784-7x4096-10" if wide else f"reference MLP 784-{hidden_units}-10"),
+        "config": {"model": (f"wide_mlp 784-7x{hidden_units}-10" if wide else f"reference MLP 784-{hidden_units}-10"),
                    "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
                    "parallelism": f"dp{world} sync_replicas R={world}, ps state sharded over {world} GPU(s)",
                    "optimizer": optimizer, "loss": "reference (softmax applied twice)", "mode": "sync",
@@ -142,22 +142,39 @@ def bench_resnet50_sync(args, rank, world, device):
     }
 
 
-def bench_mlp_async(args, rank, world, device):
+def bench_mlp_async(args, rank, world, device, wide: bool = False):
     from .parallel.async_ps import AsyncParameterServerEngine
-    batch = args.batch_size or 100
-    hidden = [args.hidden_units or 100]
-    ds = mnist.synthetic_data_sets(train_size=55000, validation_size=100, test_size=100, seed=rank)
-    state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer="sgd", lr=0.01)
+    batch = args.batch_size or (100 if not wide else 1024)
+    hidden_units = args.hidden_units or (100 if not wide else 4096)
+    hidden = [hidden_units] * (7 if wide else 1)
+    optimizer = args.optimizer or ("adam" if wide else "sgd")
+    lr = 0.01 if optimizer == "sgd" else 1e-3
+    train_rows = 55000 if not wide else max(8 * batch, 16384)
+    dtype_name = (args.dtype or "fp32") if wide else "fp32"
+    # the wide model spreads its 416 MB of state over every rank (each owns a slice), the reference model keeps
+    # the one logical ps shard of the named configuration
+    shards = world if wide else 1
+    ds = mnist.synthetic_data_sets(train_size=train_rows, validation_size=100, test_size=100, seed=rank)
+    state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer=optimizer, lr=lr)
     state.initialize(seed=1234)
     data = DeviceDataset(ds.train, device, shuffle_seed=1000 + rank)
+
+    def program(fused, gs_inc):
+        if wide:
+            cdtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+            args.no_post_update_accuracy = True
+            return WideMLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, dtype=cdtype, gs_inc=gs_inc)
+        return MLPProgram(state, data, batch, hidden, fused_update=fused, gs_inc=gs_inc,
+                          post_update_accuracy=not args.no_post_update_accuracy)
+
     if world == 1:
-        prog = MLPProgram(state, data, batch, hidden, fused_update=True, post_update_accuracy=not args.no_post_update_accuracy)
+        # one worker and its own ps: every update is applied before the next gradient is computed
+        prog = program(fused=optimizer == "sgd", gs_inc=1)
         engine = SyncReplicasEngine(prog, state)
         finish = lambda: None
     else:
-        prog = MLPProgram(state, data, batch, hidden, fused_update=False, gs_inc=0,
-                          post_update_accuracy=not args.no_post_update_accuracy)
-        engine = AsyncParameterServerEngine(prog, state, num_shards=1, staleness=4)
+        prog = program(fused=False, gs_inc=0)
+        engine = AsyncParameterServerEngine(prog, state, num_shards=shards, staleness=4)
         finish = engine.finish
     _sync_all(device, world)
     engine.run(args.warmup, 64)
@@ -172,11 +189,12 @@ def bench_mlp_async(args, rank, world, device):
     return {
         "metric": METRIC, "value": batch * args.steps * world / dt, "unit": "examples/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "fp32",
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype_name,
         "data": "synthetic MNIST-shape (resident in HBM), random-init weights",
-        "config": {"model": "reference MLP 784-100-10", "global_batch": batch * world, "per_worker_batch": batch,
-                   "seq_len": None, "parallelism": f"dp{world} async push/pull, 1 logical ps shard on rank 0, staleness 4",
-                   "optimizer": "sgd", "mode": "async", "params": state.layout.used},
+        "config": {"model": (f"wide_mlp 784-7x{hidden_units}-10" if wide else f"reference MLP 784-{hidden_units}-10"),
+                   "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
+                   "parallelism": f"dp{world} async push/pull, {shards} ps shard(s), staleness 4",
+                   "optimizer": optimizer, "mode": "async", "params": state.layout.used},
         "global_step": state.global_step() if rank == 0 else None,
     }
 
@@ -193,6 +211,8 @@ def run_benchmark(args):
         res = bench_resnet50_sync(args, rank, world, device)
     elif args.config == "mlp_async":
         res = bench_mlp_async(args, rank, world, device)
+    elif args.config == "wide_mlp_async":
+        res = bench_mlp_async(args, rank, world, device, wide=True)
     else:
         raise SystemExit(f"config {args.config} is not wired into bench.py yet")
     if world > 1:

@@ -272,36 +272,69 @@ DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s) {
 // --------------------------------------------------------------------------------------
 // helpers of the wide pipeline (pure streaming kernels)
 // --------------------------------------------------------------------------------------
-// dst[i] = src[rows[i]] converted to T, plus the transposed copy dstT[c][i]  (batch gather for layer 1)
+// dst[i] = src[rows[i]] converted to T, plus the transposed copy dstT[c][i]  (batch gather for layer 1,
+// compute copies of the weights).  64x64 tiles: 16-byte global loads, the tile held in LDS in the output
+// type, straight and transposed copies written as 8-byte (bf16) / 16-byte (fp32) pieces of 4 elements.
 template <typename T>
 __global__ __launch_bounds__(256) void gather_cast_transpose_kernel(const float* __restrict__ src, const int* __restrict__ rows,
                                                                     T* __restrict__ dst, T* __restrict__ dstT, int M, int N,
                                                                     int lds_, int ldd, int ldt) {
-  __shared__ float tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  for (int rr = ty; rr < 32; rr += 8) {
-    const int r = r0 + rr, c = c0 + tx;
-    float v = 0.f;
-    if (r < M && c < N) {
-      const int sr = rows ? rows[r] : r;
-      v = src[(size_t)sr * lds_ + c];
-      if (dst) {
-        if (sizeof(T) == 2) dst[(size_t)r * ldd + c] = (T)f2bf(v);
-        else dst[(size_t)r * ldd + c] = (T)__float_as_uint(v);
+  __shared__ T tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16 threads, 4 elements each per pass
+  const bool vec_in = ((lds_ & 3) == 0) && (((uintptr_t)src & 15) == 0);
+  const bool vec_out = dst && ((ldd & 3) == 0) && (((uintptr_t)dst & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = ty + 16 * i, r = r0 + rr, c = c0 + 4 * tx;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < M) {
+      const size_t base = (size_t)(rows ? rows[r] : r) * lds_ + c;
+      if (vec_in && c + 3 < N) {
+        const float4 q = *reinterpret_cast<const float4*>(src + base);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < N) v[j] = src[base + j];
       }
     }
-    tile[rr][tx] = v;
+    T o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = sizeof(T) == 2 ? (T)f2bf(v[j]) : (T)__float_as_uint(v[j]);
+      tile[rr][4 * tx + j] = o[j];
+    }
+    if (dst && r < M) {
+      T* d = dst + (size_t)r * ldd + c;
+      if (vec_out && c + 3 < N) {
+        if (sizeof(T) == 2) *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+        else *reinterpret_cast<uint4*>(d) = make_uint4((unsigned)o[0], (unsigned)o[1], (unsigned)o[2], (unsigned)o[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < N) d[j] = o[j];
+      }
+    }
   }
   __syncthreads();
-  if (dstT) {
-    for (int cc = ty; cc < 32; cc += 8) {
-      const int c = c0 + cc, r = r0 + tx;
-      if (c < N && r < M) {
-        const float v = tile[tx][cc];
-        if (sizeof(T) == 2) dstT[(size_t)c * ldt + r] = (T)f2bf(v);
-        else dstT[(size_t)c * ldt + r] = (T)__float_as_uint(v);
-      }
+  if (!dstT) return;
+  const bool vec_t = ((ldt & 3) == 0) && (((uintptr_t)dstT & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cc = ty + 16 * i, c = c0 + cc, r = r0 + 4 * tx;   // output row c, 4 consecutive source rows
+    if (c >= N) continue;
+    T o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = tile[4 * tx + j][cc];
+    T* d = dstT + (size_t)c * ldt + r;
+    if (vec_t && r + 3 < M) {
+      if (sizeof(T) == 2) *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+      else *reinterpret_cast<uint4*>(d) = make_uint4((unsigned)o[0], (unsigned)o[1], (unsigned)o[2], (unsigned)o[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (r + j < M) d[j] = o[j];
     }
   }
 }
@@ -310,8 +343,8 @@ DTF_EXPORT int dtf_gather_cast_transpose(const float* src, const int* rows, void
                                          int ldd, int ldt, int dtype, hipStream_t s) {
   if (!src || (!dst && !dstT)) return DTF_ERR_ARG;
   if (M <= 0 || N <= 0 || lds_ < N || (dst && ldd < N) || (dstT && ldt < M)) return DTF_ERR_SHAPE;
-  if (dtf_cdiv(M, 32) > 65535) return DTF_ERR_SHAPE;
-  dim3 grid(dtf_cdiv(N, 32), dtf_cdiv(M, 32)), block(256);
+  if (dtf_cdiv(M, 64) > 65535) return DTF_ERR_SHAPE;
+  dim3 grid(dtf_cdiv(N, 64), dtf_cdiv(M, 64)), block(256);
   if (dtype == 1)
     hipLaunchKernelGGL(gather_cast_transpose_kernel<unsigned short>, grid, block, 0, s, src, rows, (unsigned short*)dst,
                        (unsigned short*)dstT, M, N, lds_, ldd, ldt);

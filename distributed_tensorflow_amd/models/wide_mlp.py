@@ -8,7 +8,8 @@ accumulation and fp32 master weights, or in exact fp32.  Every product is of the
 
 Per step:  gather+cast batch -> L x forward GEMM (+bias, ReLU) -> head (loss, accuracy, dz)
 -> (L-1) x backward GEMM (ReLU mask) -> L x weight-gradient GEMM (+bias gradient) -> small
-kernel for the 10-class layer -> optimizer / collectives -> refresh of the compute copies.
+kernel for the 10-class layer -> optimizer / collectives.  The compute copies of the weights are
+rebuilt from the fp32 masters at the start of every step.
 """
 from __future__ import annotations
 
@@ -75,6 +76,8 @@ class WideMLPProgram(MLPProgram):
         q = self.steps_enqueued & 1
         st, B, L = self.state, self.B, len(self.names)
         rows = self.ridx[q]
+        # the master weights may have been written since the last step (optimizer, all-gather, an async pull)
+        self.refresh_compute_copies()
         ops.gather_cast_transpose(self.data.images, rows, self.xb, self.xb_t, m=B)
         x = self.xb
         for l, name in enumerate(self.names):
@@ -105,13 +108,13 @@ class WideMLPProgram(MLPProgram):
             self._tail_cpu(q, init_only=False)
         if self.after_compute is not None:
             self.after_compute()
-        self.refresh_compute_copies()
         self.steps_enqueued += 1
 
     def _count_correct(self, images, labels, rows=None, n=None, chunk: int = 8192) -> int:
         n = n if n is not None else images.shape[0]
         st, T = self.state, self.cdtype
         total = 0
+        self.refresh_compute_copies()
         for lo in range(0, n, chunk):
             m = min(chunk, n - lo)
             mp = (m + 7) // 8 * 8

@@ -16,7 +16,8 @@ slice each and are workers as well).  A worker step is
 
 and an owner runs a service thread that keeps one receive posted per remote worker on a
 dedicated two-rank communicator (so arrivals complete in any order), applies each arriving
-gradient to its slice with the fused SGD kernel, bumps ``global_step`` (owner of shard 0)
+gradient to its slice with the fused SGD (or Adam: moments live with the owner, like the slot
+variables of a ps-resident optimizer) kernel, bumps ``global_step`` (owner of shard 0)
 and sends the fresh slice back.  ``backend='nccl'`` is RCCL over xGMI; ``gloo`` runs the
 same code on CPU.  Races between an owner's compute reading its slice and the service
 thread updating it are intended (lock-free updates, as the reference's use_locking=False).
@@ -90,6 +91,12 @@ class AsyncParameterServerEngine:
         # service threads and the owner's own pushes never lose an increment
         self._gs_lock = threading.Lock()
         self._gs = 1
+        # Adam: the owner keeps the moments of its slice and counts the updates it applied (bias correction)
+        self._m = self._v = None
+        self._adam_t = 0
+        if state.optimizer == "adam" and self.is_owner:
+            self._m = torch.zeros(self.slice, dtype=f32, device=self.device)
+            self._v = torch.zeros(self.slice, dtype=f32, device=self.device)
         if self.is_owner and self.world > 1:
             self._in = {w: torch.zeros(self.slice + 2, dtype=f32, device=self.device) for w in range(self.world) if w != self.rank}
             self._out = {w: torch.zeros(self.slice + 2, dtype=f32, device=self.device) for w in range(self.world) if w != self.rank}
@@ -112,6 +119,17 @@ class AsyncParameterServerEngine:
             self._gs += 1
             self._applied += 1
             return self._gs
+
+    def _apply(self, master: torch.Tensor, grad: torch.Tensor) -> None:
+        """One lock-free optimizer application on the owned slice."""
+        st = self.state
+        if st.optimizer == "sgd":
+            ops.sgd_apply(master, grad, st.lr, 1.0)
+            return
+        with self._gs_lock:
+            self._adam_t += 1
+            t = self._adam_t
+        ops.adam_apply(master, grad, self._m, self._v, st.lr, st.beta1, st.beta2, st.eps, 1.0, step=t)
 
     def _serve(self, w: int) -> None:
         try:
@@ -137,7 +155,7 @@ class AsyncParameterServerEngine:
             gs = None
             if kind == KIND_GRAD:
                 # lock-free apply on the owned slice (ApplyGradientDescent on the ps, use_locking=False)
-                ops.sgd_apply(master, msg[:self.slice], st.lr, 1.0)
+                self._apply(master, msg[:self.slice])
                 if self.rank == 0:
                     gs = self._bump_global_step()   # global_step counts every worker's update
                 else:
@@ -175,7 +193,7 @@ class AsyncParameterServerEngine:
             lo, hi = self._shard_range(s)
             if s == self.rank:
                 if kind == KIND_GRAD:
-                    ops.sgd_apply(st.params[lo:hi], st.grads[lo:hi], st.lr, 1.0)
+                    self._apply(st.params[lo:hi], st.grads[lo:hi])
                     if s == 0:
                         st.state[0] = self._bump_global_step()
                     else:

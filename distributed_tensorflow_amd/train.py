@@ -183,8 +183,6 @@ def build_worker(role: Optional[Role], device: torch.device, datasets, hidden_un
         engine = SyncReplicasEngine(prog, state, replicas_to_aggregate=R, collective=collective)
         is_async = False
     else:
-        if optimizer != "sgd":
-            raise ValueError("async mode implements the reference's plain SGD")
         prog = MLPProgram(state, data, batch_size, hidden, loss_mode=loss_mode, fused_update=False,
                           post_update_accuracy=post_update_accuracy, gs_inc=0)
         engine = AsyncParameterServerEngine(prog, state, num_shards=num_ps, staleness=staleness)

@@ -6,7 +6,7 @@ import torch.distributed as dist
 from dist_utils import run_ranks
 
 
-def _async_worker(rank, world, port, num_shards, staleness, steps):
+def _async_worker(rank, world, port, num_shards, staleness, steps, optimizer="sgd"):
     from distributed_tensorflow_amd import ops
     from distributed_tensorflow_amd.data import mnist
     from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
@@ -14,7 +14,8 @@ def _async_worker(rank, world, port, num_shards, staleness, steps):
     from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterServerEngine
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     ds = mnist.synthetic_data_sets(train_size=1000, validation_size=100, test_size=300, seed=rank)
-    st = build_mlp_state(784, [32], 10, "cpu", world_size=world, rank=rank, lr=0.5)
+    st = build_mlp_state(784, [32], 10, "cpu", world_size=world, rank=rank, optimizer=optimizer,
+                         lr=0.5 if optimizer == "sgd" else 0.01)
     st.initialize(seed=3)
     prog = MLPProgram(st, DeviceDataset(ds.train, "cpu", shuffle_seed=rank), 50, [32], fused_update=False, gs_inc=0,
                       post_update_accuracy=False)
@@ -53,3 +54,15 @@ def test_async_counts_every_update_and_converges(world, num_shards, staleness):
         assert r["last"] < r["first"] - 0.2
         assert r["acc"] > 0.4
         assert 1 + steps <= r["gs_seen"] <= 1 + world * steps
+
+
+@pytest.mark.slow
+def test_async_adam_moments_live_with_the_owner():
+    """Adam in async mode: each owner keeps the moments of its slice and applies every arriving gradient."""
+    world, shards, steps = 3, 2, 40
+    res = run_ranks(_async_worker, world, shards, 2, steps, "adam")
+    assert res[0]["final_gs"] == 1 + world * steps
+    for r in range(shards):
+        assert res[r]["applied"] == world * steps
+    for r in res:
+        assert r["last"] < r["first"] - 0.2 and r["acc"] > 0.4

@@ -83,6 +83,19 @@ def test_gather_cast_transpose(dtype):
     assert torch.equal(dst.cpu(), want) and torch.equal(dst_t.cpu(), want.t())
 
 
+@pytest.mark.parametrize("M,N", [(37, 50), (64, 64), (130, 67), (4096, 784)])
+def test_cast_transpose_odd_shapes(M, N):
+    src = _rand(M, N, seed=3)
+    for dtype in (torch.float32, torch.bfloat16):
+        dst = torch.zeros(M, N, dtype=dtype, device=DEV)
+        dst_t = torch.zeros(N, M, dtype=dtype, device=DEV)
+        ops.gather_cast_transpose(src.to(DEV), None, dst, dst_t)
+        assert torch.equal(dst.cpu(), src.to(dtype)) and torch.equal(dst_t.cpu(), src.to(dtype).t())
+        only_t = torch.zeros(N, M, dtype=dtype, device=DEV)
+        ops.gather_cast_transpose(src.to(DEV), None, None, only_t)
+        assert torch.equal(only_t.cpu(), src.to(dtype).t())
+
+
 def test_rejects_unaligned_k():
     a = torch.zeros(16, 10, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError):
