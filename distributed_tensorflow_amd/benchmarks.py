@@ -51,7 +51,7 @@ def _max_over_ranks(value: float, device, world) -> float:
 
 
 def bench_mlp_sync(args, rank, world, device, wide: bool = False):
-    batch = args.batch_size or (100 if not wide else 1024)
+    batch = args.batch_size or (100 if not wide else 4096)
     hidden_units = args.hidden_units or (100 if not wide else 4096)
     hidden = [hidden_units] * (7 if wide else 1)
     optimizer = args.optimizer or ("adam" if wide else "sgd")
@@ -144,7 +144,7 @@ def bench_resnet50_sync(args, rank, world, device):
 
 def bench_mlp_async(args, rank, world, device, wide: bool = False):
     from .parallel.async_ps import AsyncParameterServerEngine
-    batch = args.batch_size or (100 if not wide else 1024)
+    batch = args.batch_size or (100 if not wide else 4096)
     hidden_units = args.hidden_units or (100 if not wide else 4096)
     hidden = [hidden_units] * (7 if wide else 1)
     optimizer = args.optimizer or ("adam" if wide else "sgd")

@@ -10,7 +10,7 @@
 static inline int stream_grid(int64_t nvec, int block) {
   int64_t g = (nvec + block - 1) / block;
   if (g < 1) g = 1;
-  if (g > 2048) g = 2048;
+  if (g > 1024) g = 1024;
   return (int)g;
 }
 
@@ -62,18 +62,38 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ p, 
   const float eps_t = eps * sq;
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    float4 pv = reinterpret_cast<float4*>(p)[i];
-    float4 gv = reinterpret_cast<const float4*>(g)[i];
-    float4 mv = reinterpret_cast<float4*>(m)[i];
-    float4 vv = reinterpret_cast<float4*>(v)[i];
-    adam_one(pv.x, gv.x * gscale, mv.x, vv.x, lr_t, b1, b2, eps_t);
-    adam_one(pv.y, gv.y * gscale, mv.y, vv.y, lr_t, b1, b2, eps_t);
-    adam_one(pv.z, gv.z * gscale, mv.z, vv.z, lr_t, b1, b2, eps_t);
-    adam_one(pv.w, gv.w * gscale, mv.w, vv.w, lr_t, b1, b2, eps_t);
-    reinterpret_cast<float4*>(p)[i] = pv;
-    reinterpret_cast<float4*>(m)[i] = mv;
-    reinterpret_cast<float4*>(v)[i] = vv;
+  // two independent 16-byte positions per thread and iteration (eight loads in flight before the first use);
+  // everything is touched exactly once per launch, hence the non-temporal accesses
+  f32x4* p4 = reinterpret_cast<f32x4*>(p);
+  f32x4* m4 = reinterpret_cast<f32x4*>(m);
+  f32x4* v4 = reinterpret_cast<f32x4*>(v);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += 2 * stride) {
+    const int64_t j = i + stride < nvec ? i + stride : i;      // odd tail: position i twice, second result unused
+    f32x4 pv = __builtin_nontemporal_load(p4 + i), gv = __builtin_nontemporal_load(g4 + i);
+    f32x4 mv = __builtin_nontemporal_load(m4 + i), vv = __builtin_nontemporal_load(v4 + i);
+    f32x4 pw = __builtin_nontemporal_load(p4 + j), gw = __builtin_nontemporal_load(g4 + j);
+    f32x4 mw = __builtin_nontemporal_load(m4 + j), vw = __builtin_nontemporal_load(v4 + j);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a = pv[k], b = mv[k], c = vv[k];
+      adam_one(a, gv[k] * gscale, b, c, lr_t, b1, b2, eps_t);
+      pv[k] = a; mv[k] = b; vv[k] = c;
+    }
+    __builtin_nontemporal_store(pv, p4 + i);
+    __builtin_nontemporal_store(mv, m4 + i);
+    __builtin_nontemporal_store(vv, v4 + i);
+    if (j != i) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a = pw[k], b = mw[k], c = vw[k];
+        adam_one(a, gw[k] * gscale, b, c, lr_t, b1, b2, eps_t);
+        pw[k] = a; mw[k] = b; vw[k] = c;
+      }
+      __builtin_nontemporal_store(pw, p4 + j);
+      __builtin_nontemporal_store(mw, m4 + j);
+      __builtin_nontemporal_store(vw, v4 + j);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (nvec << 2) + threadIdx.x;
