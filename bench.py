@@ -57,10 +57,22 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # a long warm-up (library autotuning, first-touch compilation) must not look like a hang: one progress line
+    # on stderr every 30 s
+    import threading
+    t_start, done = time.time(), threading.Event()
+
+    def heartbeat():
+        while not done.wait(30.0):
+            sys.stderr.write(f"[bench] {args.config}: running, {time.time() - t_start:.0f} s\n")
+            sys.stderr.flush()
+
+    threading.Thread(target=heartbeat, daemon=True).start()
     try:
         from distributed_tensorflow_amd.benchmarks import run_benchmark
         result = run_benchmark(args)
     finally:
+        done.set()
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         os.close(real_stdout)
