@@ -100,6 +100,7 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
                    "optimizer": optimizer, "loss": "reference (softmax applied twice)", "mode": "sync",
                    "collective": engine.collective if (world > 1 or force) else "none",
                    "native_rccl": engine.native_comm is not None,
+                   "peer_mapped_allreduce": getattr(engine, "p2p", None) is not None,
                    "post_update_accuracy_pass": not args.no_post_update_accuracy,
                    "hip_graph": bool(prog.use_graphs), "params": state.layout.used},
         "final_loss": last.loss,

@@ -151,7 +151,7 @@ struct DtfGemmArgs {
 // in the reference runtime).  One call enqueues every entry in order on `s`; stops at the first error
 // and returns  (entry index << 8) | error code.
 enum { DTF_OP_SMALL_GEMM = 1, DTF_OP_HEAD = 2, DTF_OP_WGRAD = 3, DTF_OP_TAIL = 4, DTF_OP_GEMM_TILED = 5, DTF_OP_UPDATE = 6,
-       DTF_OP_MLP2_FWD = 7, DTF_OP_MLP2_BWD = 8 };
+       DTF_OP_MLP2_FWD = 7, DTF_OP_MLP2_BWD = 8, DTF_OP_P2P_UPDATE = 9 };
 
 // Gradient aggregation + optimizer + parameter redistribution of one synchronous step.
 enum { DTF_UPDATE_LOCAL = 0, DTF_UPDATE_ALLREDUCE = 1, DTF_UPDATE_SHARDED = 2 };
@@ -182,6 +182,24 @@ DTF_EXPORT int dtf_comm_all_reduce_f32(void* comm, float* buf, int64_t count, hi
 DTF_EXPORT int dtf_comm_reduce_scatter_f32(void* comm, const float* send, float* recv, int64_t recvcount, hipStream_t s);
 DTF_EXPORT int dtf_comm_all_gather_f32(void* comm, const float* send, float* recv, int64_t sendcount, hipStream_t s);
 DTF_EXPORT int dtf_comm_broadcast_bytes(void* comm, void* buf, int64_t nbytes, int root, hipStream_t s);
+// One-shot all-reduce + SGD over peer-mapped buffers (p2p_allreduce.hip).
+struct DtfP2PUpdateArgs {
+  void* comm;             // dtf_p2p_create / dtf_p2p_connect
+  float* params;          // flat parameter replica, updated in place
+  float* sum_out;         // optional: the summed gradient
+  const int* seq_ptr;     // device counter with this step's number (identical on every rank, grows by one per step)
+  double timeout_s;       // wall-clock bound of the arrival wait
+  float scale;            // lr / R
+  int slot;               // 0..2, the slot the gradients of this step were written to
+};
+DTF_EXPORT void* dtf_p2p_create(int rank, int world, int64_t n_floats, char* handle_out64);
+DTF_EXPORT int dtf_p2p_connect(void* comm, const char* all_handles);
+DTF_EXPORT float* dtf_p2p_slot_ptr(void* comm, int slot);
+DTF_EXPORT int dtf_p2p_allreduce_sgd(void* comm, int slot, const int* seq_ptr, float* params, float* sum_out, float scale,
+                                     double timeout_s, hipStream_t s);
+DTF_EXPORT int dtf_p2p_update(const DtfP2PUpdateArgs* u, hipStream_t s);
+DTF_EXPORT int dtf_p2p_error(void* comm);
+DTF_EXPORT void dtf_p2p_destroy(void* comm);
 struct DtfScheduleEntry {
   int op;
   int flag;          // DTF_OP_TAIL: init_only

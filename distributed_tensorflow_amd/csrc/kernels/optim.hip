@@ -202,6 +202,7 @@ DTF_EXPORT int dtf_run_schedule(const DtfScheduleEntry* entries, int n, hipStrea
       case DTF_OP_UPDATE: rc = dtf_run_update(static_cast<const DtfUpdateArgs*>(entries[i].args), s); break;
       case DTF_OP_MLP2_FWD: rc = dtf_mlp2_fwd(static_cast<const DtfMlp2Args*>(entries[i].args), s); break;
       case DTF_OP_MLP2_BWD: rc = dtf_mlp2_bwd(static_cast<const DtfMlp2Args*>(entries[i].args), s); break;
+      case DTF_OP_P2P_UPDATE: rc = dtf_p2p_update(static_cast<const DtfP2PUpdateArgs*>(entries[i].args), s); break;
       default: rc = DTF_ERR_ARG;
     }
     if (rc != DTF_OK) return (i << 8) | rc;

@@ -101,6 +101,8 @@ class MLPProgram:
         self._call_cache: Dict = {}
         self._schedules: Dict = {}
         self.schedule_tail_entries = []   # appended by the engine: the native update entry of each step
+        self.schedule_tail_fn = None      # optional: slot -> extra entries (an update entry that depends on the slot)
+        self.grad_slots = None            # optional: one flat gradient buffer per slot (peer-mapped all-reduce)
         self._eval_buf: Dict = {}
         self._args = [self._build_args(q) for q in range(self.P)] if self.is_cuda else None
         self._started = False
@@ -135,13 +137,30 @@ class MLPProgram:
         out = {"head": head, "wgrad": wgrad, "items": items}
         if self.fused2:
             tail = ops.make_tail(st.state, perm=self.data.perm, batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
-            g = (lambda n: None) if self.fused else st.grad
+            if self.fused:
+                g = lambda n: None
+            elif self.grad_slots is not None:
+                g = lambda n: st._view(self.grad_slots[q], n)      # gradients land in this slot's exported buffer
+            else:
+                g = st.grad
             out["mlp2"] = ops.build_mlp2_args(
                 self.data.images, self.data.labels, self.xg, self.labg, self.ridx, self.hact[0], self.zpart, self.w2_snap,
                 self.ctr_snap, st.var("hid_w"), st.var("hid_b"), st.var("sm_w"), st.var("sm_b"), self.wlog, self.B, self.R,
                 self.loss_mode, q, tail, lr=st.lr if self.fused else None, dw1=g("hid_w"), db1=g("hid_b"), dw2=g("sm_w"),
                 db2=g("sm_b"))
         return out
+
+    def use_gradient_slots(self, slots) -> None:
+        """Make the two-launch step write its gradients into ``slots[slot of the step]`` (flat buffers laid out
+        like the state's gradient buffer) instead of the state's own gradient buffer."""
+        if not self.fused2 or self.fused or len(slots) != self.P:
+            raise ValueError("gradient slots need the two-launch step with stored gradients and one buffer per slot")
+        if any(t.numel() != self.state.grads.numel() or t.dtype != torch.float32 for t in slots):
+            raise ValueError("gradient slots must match the flat gradient buffer")
+        self.grad_slots = list(slots)
+        self._args = [self._build_args(q) for q in range(self.P)]
+        self._schedules.clear()
+        self._graphs.clear()
 
     def _launch_cached(self, key, build):
         """Argument structs of a launch are built once per (step parity, call site) and reused: the
@@ -185,6 +204,8 @@ class MLPProgram:
             if self.fused2:
                 entries = [(L.OP_MLP2_FWD, self._args[q]["mlp2"], 0), (L.OP_MLP2_BWD, self._args[q]["mlp2"], 0)]
                 entries.extend(self.schedule_tail_entries)
+                if self.schedule_tail_fn is not None:
+                    entries.extend(self.schedule_tail_fn(q))
                 sch = self._schedules[q] = L.Schedule(entries)
                 return sch
             for l, name in enumerate(self.names):

@@ -1,0 +1,169 @@
+"""One-shot all-reduce + SGD over peer-mapped gradient buffers (``csrc/kernels/p2p_allreduce.hip``).
+
+For the reference model one sync step exchanges 318 KB per worker (/root/reference/distributed.py:97-102):
+latency, not bandwidth.  On the xGMI full mesh of one node every GPU reads each peer's gradient slot
+directly, all links at once, and applies the averaged update in the same kernel - one hop instead of the
+2(N-1) dependent hops of a ring.
+
+Used for the small-model sync step when every rank sits on one node (SGD, all-reduce collective, RCCL
+process group); ``DTF_P2P_ALLREDUCE=0`` keeps RCCL, ``=1`` also allows it on gloo rehearsal groups.  Before
+the engine trusts it, :meth:`P2PAllReduce.self_check` runs the same kernel on throw-away buffers and
+compares with the process group's all-reduce; any mismatch, mapping failure or timed-out wait makes the
+engine keep RCCL.  Waits are bounded by a wall-clock limit (``DTF_P2P_TIMEOUT_S``, default 60 s).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from ..ops import _lib
+
+OP_P2P_UPDATE = 9
+SLOTS = 3
+HANDLE_BYTES = 64
+
+
+class P2PUpdateArgs(C.Structure):
+    _fields_ = [("comm", C.c_void_p), ("params", C.c_void_p), ("sum_out", C.c_void_p), ("seq_ptr", C.c_void_p),
+                ("timeout_s", C.c_double), ("scale", C.c_float), ("slot", C.c_int)]
+
+
+_declared = False
+
+
+def _lib_k():
+    global _declared
+    lib = _lib.kernels()
+    if not _declared:
+        lib.dtf_p2p_create.restype = C.c_void_p
+        lib.dtf_p2p_create.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_char_p]
+        lib.dtf_p2p_connect.restype = C.c_int
+        lib.dtf_p2p_connect.argtypes = [C.c_void_p, C.c_char_p]
+        lib.dtf_p2p_slot_ptr.restype = C.c_void_p
+        lib.dtf_p2p_slot_ptr.argtypes = [C.c_void_p, C.c_int]
+        lib.dtf_p2p_allreduce_sgd.restype = C.c_int
+        lib.dtf_p2p_allreduce_sgd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_double,
+                                              C.c_void_p]
+        lib.dtf_p2p_error.restype = C.c_int
+        lib.dtf_p2p_error.argtypes = [C.c_void_p]
+        lib.dtf_p2p_destroy.restype = None
+        lib.dtf_p2p_destroy.argtypes = [C.c_void_p]
+        _declared = True
+    return lib
+
+
+def requested(backend: str) -> bool:
+    mode = os.environ.get("DTF_P2P_ALLREDUCE", "auto")
+    if mode == "1":
+        return True
+    return mode == "auto" and backend == "nccl"
+
+
+def default_timeout_s() -> float:
+    return float(os.environ.get("DTF_P2P_TIMEOUT_S", "60"))
+
+
+class _DevicePtr:
+    """Minimal ``__cuda_array_interface__`` carrier so that torch can view memory it did not allocate."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class P2PAllReduce:
+    """Peer-mapped gradient slots of ``n`` floats (multiple of 4) on every rank of ``group`` (one node)."""
+
+    def __init__(self, n: int, device: torch.device, group=None, timeout_s: Optional[float] = None):
+        if n % 4:
+            raise ValueError("p2p all-reduce: element count must be a multiple of 4")
+        self.n, self.device, self.group = n, device, group
+        self.timeout_s = default_timeout_s() if timeout_s is None else timeout_s
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > 8:
+            raise ValueError("p2p all-reduce: at most 8 ranks (one node)")
+        lib = _lib_k()
+        handle = C.create_string_buffer(HANDLE_BYTES)
+        with torch.cuda.device(device):
+            self._comm = lib.dtf_p2p_create(self.rank, self.world, n, handle)
+        if not self._comm:
+            raise RuntimeError("p2p all-reduce: could not allocate / export the gradient region")
+        handles: List[Optional[bytes]] = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle.raw), group=group)
+        with torch.cuda.device(device):
+            rc = lib.dtf_p2p_connect(self._comm, b"".join(handles))
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) != 1:
+            self.close()
+            raise RuntimeError("p2p all-reduce: a rank could not map its peers' regions")
+        self.slots = [torch.as_tensor(_DevicePtr(lib.dtf_p2p_slot_ptr(self._comm, s), n), device=device) for s in range(SLOTS)]
+
+    def update_args(self, slot: int, params: torch.Tensor, seq: torch.Tensor, scale: float,
+                    sum_out: Optional[torch.Tensor] = None) -> P2PUpdateArgs:
+        """Schedule entry arguments: ``params -= scale * sum_ranks(slot)``; ``seq`` is the int32 device counter that
+        holds the step number when the entry runs (equal on every rank, growing by one per step)."""
+        if params.numel() != self.n or params.dtype != torch.float32 or not params.is_contiguous():
+            raise ValueError("p2p all-reduce: params must be the flat float32 buffer the slots were sized for")
+        return P2PUpdateArgs(comm=self._comm, params=params.data_ptr(), sum_out=_lib.ptr(sum_out), seq_ptr=seq.data_ptr(),
+                             timeout_s=self.timeout_s, scale=float(scale), slot=slot)
+
+    def allreduce_sgd(self, slot: int, params: torch.Tensor, seq: torch.Tensor, scale: float,
+                      sum_out: Optional[torch.Tensor] = None) -> None:
+        rc = _lib_k().dtf_p2p_allreduce_sgd(self._comm, slot, seq.data_ptr(), params.data_ptr(), _lib.ptr(sum_out), float(scale),
+                                            self.timeout_s, _lib.stream_handle())
+        _lib.check(rc, "p2p_allreduce_sgd")
+
+    def timed_out(self) -> bool:
+        return _lib_k().dtf_p2p_error(self._comm) != 0
+
+    def close(self) -> None:
+        if getattr(self, "_comm", None):
+            self.slots = []
+            _lib_k().dtf_p2p_destroy(self._comm)
+            self._comm = None
+
+    @staticmethod
+    def self_check(n: int, device: torch.device, group=None, rounds: int = 12) -> bool:
+        """The kernel on throw-away buffers against the process group's all-reduce, several rounds over all slots.
+        Collective: every rank calls it; every rank gets the same answer."""
+        good = 1
+        comm = None
+        try:
+            comm = P2PAllReduce(n, device, group, timeout_s=2.0)
+            rank, world = comm.rank, comm.world
+            params = torch.zeros(n, dtype=torch.float32, device=device)
+            want = torch.zeros(n, dtype=torch.float32, device=device)
+            seq = torch.zeros(1, dtype=torch.int32, device=device)
+            g = torch.Generator(device="cpu")
+            for r in range(rounds):
+                g.manual_seed(1000 * r + rank)
+                mine = torch.rand(n, generator=g).to(device)
+                slot = r % SLOTS
+                comm.slots[slot].copy_(mine)
+                seq.fill_(r + 1)
+                comm.allreduce_sgd(slot, params, seq, 0.5)
+                ref = mine.clone()
+                if dist.get_backend(group) == "nccl":
+                    dist.all_reduce(ref, group=group)
+                else:
+                    h = ref.cpu()
+                    dist.all_reduce(h, group=group)
+                    ref = h.to(device)
+                want -= 0.5 * ref
+            torch.cuda.synchronize(device)
+            if comm.timed_out() or not torch.allclose(params, want, rtol=1e-5, atol=1e-5):
+                good = 0
+        except (RuntimeError, OSError, ValueError):
+            good = 0
+        finally:
+            if comm is not None:
+                torch.cuda.synchronize(device)
+        ok = torch.tensor([good], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if comm is not None:
+            comm.close()
+        return int(ok.item()) == 1

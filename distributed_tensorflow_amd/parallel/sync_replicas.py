@@ -82,6 +82,7 @@ class SyncReplicasEngine:
         if program.fused and not (self.fast and self.world == 1):
             raise ValueError("a program with the update fused into its epilogue only fits one rank with R == 1")
         self.native_comm = None
+        self.p2p = None                         # peer-mapped one-shot all-reduce (opt-in), else None
         self._update_schedule = None
         if self.fast and not program.fused:
             program.after_compute = self._aggregate_and_apply if self.use_coll else (lambda: state.apply_shard(None, 1.0))
@@ -96,6 +97,8 @@ class SyncReplicasEngine:
         from ..ops import _lib
         st, prog = self.state, self.program
         if not nc.enabled():
+            return
+        if self.use_coll and self._try_install_p2p(group):
             return
         if self.use_coll:
             if self.coll.backend != "nccl" or group is not None:
@@ -118,6 +121,42 @@ class SyncReplicasEngine:
         else:
             self._update_schedule = _lib.Schedule([entry])
             prog.after_compute = self._update_schedule.run
+
+    def _try_install_p2p(self, group) -> bool:
+        """Single-node small-model path (DTF_P2P_ALLREDUCE=0 disables): gradients are written into peer-mapped
+        slots and one kernel per step reads every peer's slot and applies the averaged SGD update.  Every rank takes the same decision: the
+        conditions are the same everywhere and the self-check ends in a MIN all-reduce."""
+        from . import p2p_allreduce as p2p
+        import socket
+        st, prog = self.state, self.program
+        # "auto": real multi-rank RCCL groups only; "1": also one-rank groups and gloo rehearsals
+        wanted = p2p.requested("") or (p2p.requested(self.coll.backend) and self.world > 1)
+        eligible = (self.collective == "all_reduce" and st.optimizer == "sgd" and self.world <= 8
+                    and getattr(prog, "fused2", False) and not prog.fused and prog.P == p2p.SLOTS)
+        if not (wanted and eligible):
+            return False
+        hosts = [None] * self.world
+        dist.all_gather_object(hosts, socket.gethostname(), group=group)
+        if len(set(hosts)) != 1:
+            return False                            # peer mapping needs every rank on one node
+        n = st.grads.numel()
+        import warnings
+        if not p2p.P2PAllReduce.self_check(n, st.device, group):
+            warnings.warn("peer-mapped all-reduce failed its self-check on this machine; using RCCL")
+            return False
+        try:
+            self.p2p = p2p.P2PAllReduce(n, st.device, group)
+        except RuntimeError as e:                   # collective failure: raised on every rank
+            warnings.warn(f"peer-mapped all-reduce unavailable ({e}); using RCCL")
+            return False
+        prog.use_gradient_slots(self.p2p.slots)
+        # the step number the update kernel publishes: local_step after the tail's increment (equal on all ranks)
+        seq = st.state[1:2]
+        self._p2p_args = [self.p2p.update_args(q, st.params, seq, st.lr / self.R) for q in range(prog.P)]
+        prog.schedule_tail_fn = lambda q: [(p2p.OP_P2P_UPDATE, self._p2p_args[q], 0)]
+        prog._schedules.clear()
+        prog.after_compute = None
+        return True
 
     # ------------------------------------------------------------------ fast path (R == num_workers)
     def _aggregate_and_apply(self) -> None:
@@ -148,6 +187,8 @@ class SyncReplicasEngine:
             else:
                 self.program.run(n_steps, graph_steps)
             self.updates_applied += n_steps
+            if self.p2p is not None and self.p2p.timed_out():
+                raise RuntimeError("peer-mapped all-reduce: a peer's gradients did not arrive within the time limit")
             return
         for _ in range(n_steps):
             self._general_update()

@@ -235,3 +235,33 @@ def test_gpu_two_launch_step_matches_three_launch_step(monkeypatch, hidden, batc
         torch.testing.assert_close(st_2.grads, st_3.grads, rtol=1e-4, atol=1e-7)
     assert st_2.global_step() == steps + 1 and st_2.local_step() == steps
     assert prog_2.post_correct_of_last_step() == prog_3.post_correct_of_last_step()
+
+
+@pytest.mark.gpu
+def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch):
+    """DTF_P2P_ALLREDUCE=1 on a one-rank group: gradients go through the exported slot buffers and the one-shot
+    update kernel (captured in the step graph); the trajectory must equal the fused local update."""
+    import torch.distributed as dist
+    from dist_utils import free_port
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=200, test_size=300, seed=5)
+
+    def make(p2p):
+        monkeypatch.setenv("DTF_P2P_ALLREDUCE", "1" if p2p else "0")
+        st = build_mlp_state(784, [100], 10, "cuda", lr=0.3)
+        st.initialize(seed=11)
+        prog = MLPProgram(st, DeviceDataset(ds.train, "cuda", shuffle_seed=5), 100, [100], fused_update=not p2p)
+        eng = SyncReplicasEngine(prog, st, collective="all_reduce", force_collectives=p2p)
+        eng.run(30, 8)
+        torch.cuda.synchronize()
+        return st, prog, eng
+
+    st_p, prog_p, eng_p = make(True)
+    st_f, prog_f, eng_f = make(False)
+    assert eng_p.p2p is not None and prog_p.after_compute is None and eng_f.p2p is None
+    for a, b in zip(prog_p.read_log(0, 30), prog_f.read_log(0, 30)):
+        assert abs(a.loss - b.loss) < 1e-5 and a.global_step == b.global_step
+    torch.testing.assert_close(st_p.params, st_f.params, rtol=1e-5, atol=1e-6)

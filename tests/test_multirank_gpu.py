@@ -12,7 +12,9 @@ from test_cli import COMMON, _finish, _launch, _steps
 pytestmark = pytest.mark.gpu
 
 
-def _sync_gpu(rank, world, port, collective):
+def _sync_gpu(rank, world, port, collective, p2p=False):
+    if p2p:
+        os.environ["DTF_P2P_ALLREDUCE"] = "1"
     from distributed_tensorflow_amd.data import mnist
     from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
     from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
@@ -27,7 +29,8 @@ def _sync_gpu(rank, world, port, collective):
     eng.run(20)
     torch.cuda.synchronize()
     recs = prog.read_log(0, 20)
-    out = {"params": st.params.cpu().numpy().copy(), "gs": st.global_step(), "first": recs[0].loss, "last": recs[-1].loss}
+    out = {"params": st.params.cpu().numpy().copy(), "gs": st.global_step(), "first": recs[0].loss, "last": recs[-1].loss,
+           "p2p": eng.p2p is not None}
     dist.barrier()
     dist.destroy_process_group()
     return out
@@ -81,3 +84,34 @@ def test_host_backend_with_gpu_worker():
     st = _steps(lines)
     assert [s[1] for s in st] == list(range(1, 26))
     assert st[-1][2] < st[0][2] - 0.3
+
+
+def _p2p_rank(rank, world, port):
+    from distributed_tensorflow_amd.parallel.p2p_allreduce import P2PAllReduce
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ok = P2PAllReduce.self_check(79616, dev, rounds=9)
+    dist.barrier()
+    dist.destroy_process_group()
+    return {"ok": ok}
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_allreduce_between_processes_sharing_the_gpu(world):
+    """IPC mapping, flag protocol and reduction order of the one-shot all-reduce, rehearsed with several
+    processes on the one GPU of the test box (the peers' regions are then IPC-mapped memory of the same device)."""
+    res = run_ranks(_p2p_rank, world)
+    assert all(r["ok"] for r in res)
+
+
+def test_two_ranks_sync_with_peer_mapped_allreduce():
+    """The whole engine path of the opt-in one-shot all-reduce: self-check, gradients written into the exported
+    slots by the backward launch, one update kernel per step; against the same run over the process group."""
+    a, b = run_ranks(_sync_gpu, 2, "all_reduce", True)
+    c, d = run_ranks(_sync_gpu, 2, "all_reduce", False)
+    assert a["p2p"] and b["p2p"] and not c["p2p"]
+    assert (a["params"] == b["params"]).all()              # replicas stay bit-identical
+    assert a["gs"] == b["gs"] == 21
+    import numpy as np
+    np.testing.assert_allclose(a["params"], c["params"], rtol=1e-4, atol=1e-6)
