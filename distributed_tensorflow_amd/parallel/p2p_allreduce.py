@@ -89,17 +89,19 @@ class P2PAllReduce:
         handle = C.create_string_buffer(HANDLE_BYTES)
         with torch.cuda.device(device):
             self._comm = lib.dtf_p2p_create(self.rank, self.world, n, handle)
-        if not self._comm:
-            raise RuntimeError("p2p all-reduce: could not allocate / export the gradient region")
+        # A failure on one rank must not leave the others waiting in a collective: every rank goes through the
+        # same exchanges and all of them learn the outcome together.
         handles: List[Optional[bytes]] = [None] * self.world
-        dist.all_gather_object(handles, bytes(handle.raw), group=group)
-        with torch.cuda.device(device):
-            rc = lib.dtf_p2p_connect(self._comm, b"".join(handles))
-        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_gather_object(handles, bytes(handle.raw) if self._comm else b"", group=group)
+        good = bool(self._comm) and all(len(h) == HANDLE_BYTES for h in handles)
+        if good:
+            with torch.cuda.device(device):
+                good = lib.dtf_p2p_connect(self._comm, b"".join(handles)) == 0
+        ok = torch.tensor([1 if good else 0], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if int(ok.item()) != 1:
             self.close()
-            raise RuntimeError("p2p all-reduce: a rank could not map its peers' regions")
+            raise RuntimeError("p2p all-reduce: a rank could not allocate, export or map the gradient regions")
         self.slots = [torch.as_tensor(_DevicePtr(lib.dtf_p2p_slot_ptr(self._comm, s), n), device=device) for s in range(SLOTS)]
 
     def update_args(self, slot: int, params: torch.Tensor, seq: torch.Tensor, scale: float,
@@ -132,36 +134,48 @@ class P2PAllReduce:
         Collective: every rank calls it; every rank gets the same answer."""
         good = 1
         comm = None
+        rank = dist.get_rank(group)
+        nccl = dist.get_backend(group) == "nccl"
+        gen = torch.Generator(device="cpu")
+
+        def contribution(r: int) -> torch.Tensor:
+            gen.manual_seed(1000 * r + rank)
+            return torch.rand(n, generator=gen).to(device)
+
+        params = torch.zeros(n, dtype=torch.float32, device=device)
         try:
-            comm = P2PAllReduce(n, device, group, timeout_s=2.0)
-            rank, world = comm.rank, comm.world
-            params = torch.zeros(n, dtype=torch.float32, device=device)
-            want = torch.zeros(n, dtype=torch.float32, device=device)
-            seq = torch.zeros(1, dtype=torch.int32, device=device)
-            g = torch.Generator(device="cpu")
-            for r in range(rounds):
-                g.manual_seed(1000 * r + rank)
-                mine = torch.rand(n, generator=g).to(device)
-                slot = r % SLOTS
-                comm.slots[slot].copy_(mine)
-                seq.fill_(r + 1)
-                comm.allreduce_sgd(slot, params, seq, 0.5)
-                ref = mine.clone()
-                if dist.get_backend(group) == "nccl":
-                    dist.all_reduce(ref, group=group)
-                else:
-                    h = ref.cpu()
-                    dist.all_reduce(h, group=group)
-                    ref = h.to(device)
-                want -= 0.5 * ref
-            torch.cuda.synchronize(device)
-            if comm.timed_out() or not torch.allclose(params, want, rtol=1e-5, atol=1e-5):
-                good = 0
+            comm = P2PAllReduce(n, device, group, timeout_s=2.0)      # raises on every rank or on none
         except (RuntimeError, OSError, ValueError):
             good = 0
-        finally:
-            if comm is not None:
+        if comm is not None:
+            try:
+                # all rounds back to back, with nothing but the kernel's own flags keeping the ranks in step
+                # (slots are reused every third round)
+                seq = torch.zeros(1, dtype=torch.int32, device=device)
+                for r in range(rounds):
+                    slot = r % SLOTS
+                    comm.slots[slot].copy_(contribution(r))
+                    seq.fill_(r + 1)
+                    comm.allreduce_sgd(slot, params, seq, 0.5)
                 torch.cuda.synchronize(device)
+                if comm.timed_out():
+                    good = 0
+            except (RuntimeError, OSError, ValueError):
+                good = 0
+        # the reference result through the process group; every rank runs these collectives whatever happened above
+        want = torch.zeros(n, dtype=torch.float32, device=device)
+        for r in range(rounds):
+            ref = contribution(r)
+            if nccl:
+                dist.all_reduce(ref, group=group)
+            else:
+                h = ref.cpu()
+                dist.all_reduce(h, group=group)
+                ref = h.to(device)
+            want -= 0.5 * ref
+        if good and not torch.allclose(params, want, rtol=1e-5, atol=1e-5):
+            good = 0
+        torch.cuda.synchronize(device)
         ok = torch.tensor([good], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if comm is not None:
