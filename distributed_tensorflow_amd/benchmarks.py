@@ -148,7 +148,7 @@ def bench_resnet50_sync(args, rank, world, device):
 
 
 def bench_mlp_async(args, rank, world, device, wide: bool = False):
-    from .parallel.async_ps import AsyncParameterServerEngine
+    from .parallel.async_peer import make_async_engine
     batch = args.batch_size or (100 if not wide else 4096)
     hidden_units = args.hidden_units or (100 if not wide else 4096)
     hidden = [hidden_units] * (7 if wide else 1)
@@ -179,7 +179,7 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
         finish = lambda: None
     else:
         prog = program(fused=False, gs_inc=0)
-        engine = AsyncParameterServerEngine(prog, state, num_shards=shards, staleness=4)
+        engine = make_async_engine(prog, state, shards, 4)
         finish = engine.finish
     _sync_all(device, world)
     engine.run(args.warmup, 64)
@@ -198,8 +198,8 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
         "data": "synthetic MNIST-shape (resident in HBM), random-init weights",
         "config": {"model": (f"wide_mlp 784-7x{hidden_units}-10" if wide else f"reference MLP 784-{hidden_units}-10"),
                    "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
-                   "parallelism": f"dp{world} async push/pull, {shards} ps shard(s), staleness 4",
-                   "optimizer": optimizer, "mode": "async", "params": state.layout.used},
+                   "parallelism": f"dp{world} async push/pull, {shards} ps shard(s), staleness {getattr(engine, 'staleness', 0)}",
+                   "optimizer": optimizer, "mode": "async", "engine": type(engine).__name__, "params": state.layout.used},
         "global_step": state.global_step() if rank == 0 else None,
     }
 

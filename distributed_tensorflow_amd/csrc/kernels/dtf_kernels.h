@@ -151,7 +151,7 @@ struct DtfGemmArgs {
 // in the reference runtime).  One call enqueues every entry in order on `s`; stops at the first error
 // and returns  (entry index << 8) | error code.
 enum { DTF_OP_SMALL_GEMM = 1, DTF_OP_HEAD = 2, DTF_OP_WGRAD = 3, DTF_OP_TAIL = 4, DTF_OP_GEMM_TILED = 5, DTF_OP_UPDATE = 6,
-       DTF_OP_MLP2_FWD = 7, DTF_OP_MLP2_BWD = 8, DTF_OP_P2P_UPDATE = 9 };
+       DTF_OP_MLP2_FWD = 7, DTF_OP_MLP2_BWD = 8, DTF_OP_P2P_UPDATE = 9, DTF_OP_ASYNC_PUSH_PULL = 10 };
 
 // Gradient aggregation + optimizer + parameter redistribution of one synchronous step.
 enum { DTF_UPDATE_LOCAL = 0, DTF_UPDATE_ALLREDUCE = 1, DTF_UPDATE_SHARDED = 2 };
@@ -200,6 +200,24 @@ DTF_EXPORT int dtf_p2p_allreduce_sgd(void* comm, int slot, const int* seq_ptr, f
 DTF_EXPORT int dtf_p2p_update(const DtfP2PUpdateArgs* u, hipStream_t s);
 DTF_EXPORT int dtf_p2p_error(void* comm);
 DTF_EXPORT void dtf_p2p_destroy(void* comm);
+// Asynchronous push/pull over peer-mapped parameter slices (p2p_allreduce.hip).
+struct DtfAsyncPushPullArgs {
+  float* master[8];       // slice s of the parameters in the (mapped) region of its owner
+  int* counters[8];       // per owner: [0] global_step (meaningful for shard 0), [1] updates applied to the slice
+  const float* grads;     // local flat gradients [shards * slice]
+  float* params;          // local flat parameter replica, refreshed by the pull
+  int* state;             // local counters: state[0] receives global_step
+  int64_t slice;          // floats per slice (multiple of 4)
+  int shards;
+  int mode;               // 0: push (apply lr * grads) + pull, 1: pull only
+  float lr;
+  int pad_;
+};
+DTF_EXPORT int dtf_async_push_pull(const DtfAsyncPushPullArgs* a, hipStream_t s);
+DTF_EXPORT void* dtf_ipc_alloc(int64_t bytes, char* handle_out64);
+DTF_EXPORT void* dtf_ipc_open(const char* handle64);
+DTF_EXPORT int dtf_ipc_close(void* p);
+DTF_EXPORT int dtf_ipc_free(void* p);
 struct DtfScheduleEntry {
   int op;
   int flag;          // DTF_OP_TAIL: init_only

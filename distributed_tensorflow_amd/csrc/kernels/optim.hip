@@ -203,6 +203,7 @@ DTF_EXPORT int dtf_run_schedule(const DtfScheduleEntry* entries, int n, hipStrea
       case DTF_OP_MLP2_FWD: rc = dtf_mlp2_fwd(static_cast<const DtfMlp2Args*>(entries[i].args), s); break;
       case DTF_OP_MLP2_BWD: rc = dtf_mlp2_bwd(static_cast<const DtfMlp2Args*>(entries[i].args), s); break;
       case DTF_OP_P2P_UPDATE: rc = dtf_p2p_update(static_cast<const DtfP2PUpdateArgs*>(entries[i].args), s); break;
+      case DTF_OP_ASYNC_PUSH_PULL: rc = dtf_async_push_pull(static_cast<const DtfAsyncPushPullArgs*>(entries[i].args), s); break;
       default: rc = DTF_ERR_ARG;
     }
     if (rc != DTF_OK) return (i << 8) | rc;

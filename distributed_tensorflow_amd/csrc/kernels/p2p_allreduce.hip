@@ -191,3 +191,80 @@ DTF_EXPORT void dtf_p2p_destroy(void* comm) {
   (void)hipFree(c->err);
   delete c;
 }
+
+// ------------------------------------------------------------------------------------------
+// Asynchronous (Hogwild) push/pull over peer-mapped parameter slices.
+//
+// The reference's async mode (/root/reference/distributed.py:89, :102 without --sync_replicas) lets every
+// worker apply its gradient to the ps-resident variables the moment it is computed, without locks, and read
+// the variables back for its next step.  Here the ps-resident variables are slices of the flat parameter
+// buffer living in the exported region of their owner rank; a worker applies its gradient with ONE kernel
+// that walks every slice through its mapped pointer: read master, subtract lr*g, write master (the lock-free
+// read-modify-write of use_locking=False, now over xGMI), and keep the fresh value as the local replica (the
+// pull).  global_step is a counter in the region of shard 0, bumped with a system-scope atomic.  No host
+// thread, no receive loop on the owner, nothing to wait for.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void async_push_pull_kernel(DtfAsyncPushPullArgs a) {
+  const int64_t slice4 = a.slice >> 2;
+  const int64_t total4 = slice4 * a.shards;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+    const int s = (int)(i / slice4);
+    f32x4* m = reinterpret_cast<f32x4*>(a.master[s]) + (i - (int64_t)s * slice4);
+    f32x4 v = __builtin_nontemporal_load(m);
+    if (a.mode == 0) {
+      v -= a.lr * reinterpret_cast<const f32x4*>(a.grads)[i];
+      __builtin_nontemporal_store(v, m);
+    }
+    reinterpret_cast<f32x4*>(a.params)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int gs;
+    if (a.mode == 0) {
+      gs = __hip_atomic_fetch_add(a.counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
+      for (int s = 0; s < a.shards; ++s) __hip_atomic_fetch_add(a.counters[s] + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      gs = __hip_atomic_load(a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    a.state[0] = gs;      // global_step as the ps holds it after this worker's update
+  }
+}
+}  // namespace
+
+DTF_EXPORT int dtf_async_push_pull(const DtfAsyncPushPullArgs* a, hipStream_t s) {
+  if (!a || !a->params || !a->state || a->shards < 1 || a->shards > 8 || a->slice <= 0 || (a->slice & 3)) return DTF_ERR_ARG;
+  if (a->mode == 0 && !a->grads) return DTF_ERR_ARG;
+  for (int i = 0; i < a->shards; ++i)
+    if (!a->master[i] || !a->counters[i]) return DTF_ERR_ARG;
+  if (!dtf_aligned16(a->params) || (a->grads && !dtf_aligned16(a->grads))) return DTF_ERR_ALIGN;
+  const int64_t total4 = (a->slice >> 2) * a->shards;
+  int grid = (int)((total4 + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(async_push_pull_kernel, dim3(grid), dim3(256), 0, s, *a);
+  return dtf_check_launch();
+}
+
+// Uncached device memory that other processes of the node can map: allocation + 64-byte IPC handle.
+DTF_EXPORT void* dtf_ipc_alloc(int64_t bytes, char* handle_out64) {
+  if (bytes <= 0 || !handle_out64) return nullptr;
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached) != hipSuccess) return nullptr;
+  hipIpcMemHandle_t h;
+  if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&h, p) != hipSuccess) {
+    (void)hipFree(p);
+    return nullptr;
+  }
+  memcpy(handle_out64, &h, sizeof(h));
+  return p;
+}
+DTF_EXPORT void* dtf_ipc_open(const char* handle64) {
+  if (!handle64) return nullptr;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof(h));
+  void* p = nullptr;
+  if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return nullptr;
+  return p;
+}
+DTF_EXPORT int dtf_ipc_close(void* p) { return p && hipIpcCloseMemHandle(p) == hipSuccess ? DTF_OK : DTF_ERR_ARG; }
+DTF_EXPORT int dtf_ipc_free(void* p) { return p && hipFree(p) == hipSuccess ? DTF_OK : DTF_ERR_ARG; }

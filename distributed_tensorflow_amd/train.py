@@ -26,6 +26,7 @@ from .cluster.spec import ClusterSpec, Role, split_hosts, validate_role
 from .data import mnist
 from .data.device_dataset import DeviceDataset
 from .models.mlp import MLPProgram, StepRecord, build_mlp_state
+from .parallel.async_peer import make_async_engine
 from .utils import trace
 from .parallel.async_ps import AsyncParameterServerEngine
 from .parallel.sync_replicas import SyncReplicasEngine
@@ -185,7 +186,7 @@ def build_worker(role: Optional[Role], device: torch.device, datasets, hidden_un
     else:
         prog = MLPProgram(state, data, batch_size, hidden, loss_mode=loss_mode, fused_update=False,
                           post_update_accuracy=post_update_accuracy, gs_inc=0)
-        engine = AsyncParameterServerEngine(prog, state, num_shards=num_ps, staleness=staleness)
+        engine = make_async_engine(prog, state, num_ps, staleness)     # device-side push/pull where it applies
         is_async = True
     return state, prog, engine, is_async
 

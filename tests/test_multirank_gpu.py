@@ -115,3 +115,51 @@ def test_two_ranks_sync_with_peer_mapped_allreduce():
     assert a["gs"] == b["gs"] == 21
     import numpy as np
     np.testing.assert_allclose(a["params"], c["params"], rtol=1e-4, atol=1e-6)
+
+
+def _peer_async_gpu(rank, world, port, shards):
+    os.environ["DTF_PEER_ASYNC"] = "1"
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.async_peer import PeerMappedAsyncEngine, make_async_engine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=100, test_size=300, seed=rank)
+    st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, lr=0.5)
+    st.initialize(seed=3)
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=rank), 100, [100], fused_update=False, gs_inc=0,
+                      post_update_accuracy=False)
+    eng = make_async_engine(prog, st, shards, 2)
+    kind = type(eng).__name__
+    eng.run(24, 8)                      # graph-replayed launches of steps
+    for _ in range(6):
+        eng.step()
+    torch.cuda.synchronize()
+    dist.barrier()                      # everybody has pushed everything
+    gs = eng.sync_params()
+    recs = prog.read_log(0, 30)
+    params = st.params.cpu().numpy().copy()
+    eng.finish()
+    out = {"kind": kind, "gs": gs, "first": recs[0].loss, "last": recs[-1].loss, "applied": eng.updates_applied_here,
+           "params": params, "gs_seen": [r.global_step for r in recs]}
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+@pytest.mark.parametrize("world,shards", [(3, 1), (4, 2)])
+def test_peer_mapped_async_engine_on_one_gpu(world, shards):
+    """Device-side Hogwild: every worker applies its gradients to the owners' mapped slices with one kernel per
+    step; global_step counts all updates; after the last push everybody pulls the same parameters."""
+    res = run_ranks(_peer_async_gpu, world, shards)
+    assert all(r["kind"] == "PeerMappedAsyncEngine" for r in res)
+    assert all(r["gs"] == 1 + world * 30 for r in res)
+    for r in range(shards):
+        assert res[r]["applied"] == world * 30
+    for r in res[1:]:
+        assert (r["params"] == res[0]["params"]).all()
+    for r in res:
+        assert r["last"] < r["first"] - 0.3
+        assert all(b >= a for a, b in zip(r["gs_seen"], r["gs_seen"][1:]))      # the counter a worker sees never goes back
