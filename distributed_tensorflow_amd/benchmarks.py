@@ -172,7 +172,18 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
         return MLPProgram(state, data, batch, hidden, fused_update=fused, gs_inc=gs_inc,
                           post_update_accuracy=not args.no_post_update_accuracy)
 
-    if world == 1:
+    force = bool(getattr(args, "force_collectives", False)) and world == 1 and device.type == "cuda" and not wide
+    if force:
+        # N=1 only: the multi-rank code path (gradients stored, push/pull kernel through the exported region)
+        from .parallel.async_peer import PeerMappedAsyncEngine
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29534")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        prog = program(fused=False, gs_inc=0)
+        engine = PeerMappedAsyncEngine(prog, state, 1)
+        finish = engine.finish
+    elif world == 1:
         # one worker and its own ps: every update is applied before the next gradient is computed
         prog = program(fused=optimizer == "sgd", gs_inc=1)
         engine = SyncReplicasEngine(prog, state)
@@ -186,7 +197,7 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
     _sync_all(device, world)
     t0 = time.perf_counter()
     engine.run(args.steps, 64)
-    if world > 1:
+    if world > 1 or force:
         engine.sync_params()
     _sync_all(device, world)
     dt = _max_over_ranks(time.perf_counter() - t0, device, world)
