@@ -2,6 +2,7 @@
 """Per-kernel latency of the reference MLP step (each kernel replayed from its own hipGraph)."""
 import argparse
 import sys, os
+os.environ.setdefault("DTF_FUSED_STEP", "0")      # this tool times the kernels of the general three-launch step
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from distributed_tensorflow_amd import ops
