@@ -143,14 +143,7 @@ class PeerMappedAsyncEngine:
         if not all_ok(self._startup_check()):
             self._release()
             raise PeerMappedUnavailable("the peer-mapped push/pull failed its start-up check on this machine")
-        # ---- the owners publish their slices and the step counter ----
-        if self.is_owner:
-            lo = self.rank * self.slice
-            self._master_view().copy_(state.params[lo:lo + self.slice])
-            self._counter_view()[0:2] = torch.tensor([state.global_step() if self.rank == 0 else 0, 0], dtype=torch.int32,
-                                                      device=self.device)
-        torch.cuda.synchronize(self.device)
-        self._barrier()
+        self.publish_state()
         entry = (OP_ASYNC_PUSH_PULL, self._push, 0)
         if hasattr(program, "schedule_tail_entries"):
             program.schedule_tail_entries.append(entry)
@@ -210,6 +203,20 @@ class PeerMappedAsyncEngine:
         st.grads.copy_(keep_g)
         st.state.copy_(keep_s)
         return ok
+
+    def publish_state(self) -> None:
+        """The owners (re)publish their slices and the step counter from their local state.  Collective; called at
+        construction and again by the training script once the chief has initialised or restored the variables."""
+        st = self.state
+        torch.cuda.synchronize(self.device)
+        self._barrier()                                   # nobody is pushing any more
+        if self.is_owner:
+            lo = self.rank * self.slice
+            self._master_view().copy_(st.params[lo:lo + self.slice])
+            self._counter_view()[0:2] = torch.tensor([st.global_step() if self.rank == 0 else 0, 0], dtype=torch.int32,
+                                                      device=self.device)
+        torch.cuda.synchronize(self.device)
+        self._barrier()
 
     # ------------------------------------------------------------------ engine interface
     def step(self) -> None:

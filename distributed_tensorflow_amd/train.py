@@ -166,9 +166,22 @@ class TrainingLoop:
 def build_worker(role: Optional[Role], device: torch.device, datasets, hidden_units: int, batch_size: int,
                  learning_rate: float, sync_replicas: bool, replicas_to_aggregate: Optional[int], world: int, rank: int,
                  optimizer: str = "sgd", loss: str = "reference", post_update_accuracy: bool = True, hidden_layers: int = 1,
-                 staleness: int = 4, num_ps: int = 1, seed: int = 0, collective: str = "auto"):
+                 staleness: int = 4, num_ps: int = 1, seed: int = 0, collective: str = "auto", model: str = "mlp",
+                 dtype: str = "fp32"):
     """Graph construction of distributed.py:60-102, as device-side state + step program + engine."""
+    if model not in ("mlp", "wide_mlp"):
+        raise ValueError(f"--model={model}: this script trains 'mlp' and 'wide_mlp' on MNIST-shape data "
+                         "(ResNet-50 runs through bench.py --config resnet50_sync)")
     hidden = [hidden_units] * max(1, hidden_layers)
+
+    def make_program(fused: bool, gs_inc: int):
+        if model == "wide_mlp":
+            from .models.wide_mlp import WideMLPProgram
+            cdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+            return WideMLPProgram(state, data, batch_size, hidden, loss_mode=loss_mode, dtype=cdtype, gs_inc=gs_inc)
+        return MLPProgram(state, data, batch_size, hidden, loss_mode=loss_mode, fused_update=fused,
+                          post_update_accuracy=post_update_accuracy, gs_inc=gs_inc)
+
     state = build_mlp_state(IMAGE_PIXELS * IMAGE_PIXELS, hidden, 10, device, world_size=world, rank=rank,
                             optimizer=optimizer, lr=learning_rate)
     data = DeviceDataset(datasets.train, device, shuffle_seed=(seed * 7919 + rank))
@@ -178,14 +191,12 @@ def build_worker(role: Optional[Role], device: torch.device, datasets, hidden_un
         if not sync_replicas:
             R = 1
         fast = (R == world)
-        fused = fast and world == 1 and optimizer == "sgd"
-        prog = MLPProgram(state, data, batch_size, hidden, loss_mode=loss_mode, fused_update=fused,
-                          post_update_accuracy=post_update_accuracy, gs_inc=1 if fast else 0)
+        fused = fast and world == 1 and optimizer == "sgd" and model == "mlp"
+        prog = make_program(fused, 1 if fast else 0)
         engine = SyncReplicasEngine(prog, state, replicas_to_aggregate=R, collective=collective)
         is_async = False
     else:
-        prog = MLPProgram(state, data, batch_size, hidden, loss_mode=loss_mode, fused_update=False,
-                          post_update_accuracy=post_update_accuracy, gs_inc=0)
+        prog = make_program(False, 0)
         engine = make_async_engine(prog, state, num_ps, staleness)     # device-side push/pull where it applies
         is_async = True
     return state, prog, engine, is_async
@@ -231,8 +242,9 @@ def main(unused_argv=None) -> int:
         role, device, datasets, FLAGS.hidden_units, FLAGS.batch_size, FLAGS.learning_rate, FLAGS.sync_replicas,
         FLAGS.replicas_to_aggregate, num_workers, FLAGS.task_index, optimizer=FLAGS.optimizer, loss=FLAGS.loss,
         post_update_accuracy=FLAGS.post_update_accuracy, hidden_layers=FLAGS.hidden_layers, staleness=FLAGS.staleness,
-        num_ps=max(1, len(ps_spec)), seed=FLAGS.seed)
+        num_ps=max(1, len(ps_spec)), seed=FLAGS.seed, model=FLAGS.model, dtype=FLAGS.dtype)
 
+    sys.stderr.write("Worker %d: update engine %s\n" % (FLAGS.task_index, type(engine).__name__))   # not a reference line
     seed = FLAGS.seed if FLAGS.seed else (int(time.time() * 1000) & 0x7FFFFFFF)
     sv = Supervisor(is_chief=is_chief, logdir=FLAGS.train_dir, init_fn=lambda: state.initialize(seed), state=state,
                     recovery_wait_secs=1, save_model_secs=FLAGS.save_model_secs, store=server.store,
@@ -242,6 +254,8 @@ def main(unused_argv=None) -> int:
     else:
         print('Worker %d: Waiting for session to be initaialized...' % FLAGS.task_index)   # :124
     sv.prepare_or_wait_for_session()                                                       # :125
+    if hasattr(engine, "publish_state"):
+        engine.publish_state()        # ps-resident copies of the variables are taken from the initialised state
     print('Worker %d: Session initialization  complete.' % FLAGS.task_index)               # :126
 
     if FLAGS.sync_replicas and is_chief:

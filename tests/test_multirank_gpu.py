@@ -163,3 +163,24 @@ def test_peer_mapped_async_engine_on_one_gpu(world, shards):
     for r in res:
         assert r["last"] < r["first"] - 0.3
         assert all(b >= a for a, b in zip(r["gs_seen"], r["gs_seen"][1:]))      # the counter a worker sees never goes back
+
+
+def test_cli_async_workers_use_the_device_side_engine(monkeypatch):
+    """Reference launch recipe, async mode, two workers sharing the GPU: the script picks the peer-mapped engine,
+    republishes the ps-resident copies after the chief's initialisation, and global_step counts both workers."""
+    monkeypatch.setenv("DTF_PEER_ASYNC", "1")
+    ps_port, w0, w1 = free_port(), free_port(), free_port()
+    args = ["--ps_hosts=127.0.0.1:%d" % ps_port, "--worker_hosts=127.0.0.1:%d,127.0.0.1:%d" % (w0, w1), "--train_steps=60",
+            "--dist_backend=gloo"] + [a for a in COMMON if not a.startswith("--device")] + ["--device=gpu"]
+    ps = _launch(["--job_name=ps", "--task_index=0"] + args)
+    p1 = _launch(["--job_name=worker", "--task_index=1"] + args)
+    p0 = _launch(["--job_name=worker", "--task_index=0"] + args)
+    (o0, e0), (o1, e1) = p0.communicate(timeout=300), p1.communicate(timeout=300)
+    _finish(ps)
+    assert p0.returncode == 0 and p1.returncode == 0, e0[-2000:] + e1[-2000:]
+    assert "update engine PeerMappedAsyncEngine" in e0 and "update engine PeerMappedAsyncEngine" in e1
+    s0, s1 = _steps(o0.splitlines()), _steps(o1.splitlines())
+    assert s0 and s1
+    gs = sorted([s[1] for s in s0] + [s[1] for s in s1])
+    assert gs[-1] >= 60 and len(s0) + len(s1) >= 59            # the two workers share the 60 updates
+    assert s0[-1][2] < s0[0][2] - 0.2 and s1[-1][2] < s1[0][2] - 0.2
