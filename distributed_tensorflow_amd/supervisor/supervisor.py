@@ -70,9 +70,12 @@ class Supervisor:
                 time.sleep(self.recovery_wait_secs)
         if self.group_size > 1 and dist.is_initialized():
             # every worker receives the chief's variables (the reference's workers read them from the ps)
-            dist.broadcast(st.params, src=0)
-            dist.broadcast(st.state, src=0)
+            from ..parallel.comm import Collectives
+            coll = Collectives()          # stages GPU tensors through the host on gloo rehearsal groups
+            coll.broadcast(st.params, 0)
+            coll.broadcast(st.state, 0)
             st.initialized = True
+            st.version += 1
         self._last_save = time.time()
         self._last_rate_time = time.time()
         self._last_rate_step = None
