@@ -75,7 +75,6 @@ class Supervisor:
             coll.broadcast(st.params, 0)
             coll.broadcast(st.state, 0)
             st.initialized = True
-            st.version += 1
         self._last_save = time.time()
         self._last_rate_time = time.time()
         self._last_rate_step = None
