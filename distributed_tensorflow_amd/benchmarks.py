@@ -25,6 +25,8 @@ def _setup_distributed(args):
     if args.cpu or not torch.cuda.is_available():
         device = torch.device("cpu")
     else:
+        if os.environ.get("DTF_SHARE_GPU") == "1":      # rehearsal of an N-rank launch on a box with fewer GPUs
+            local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     if world > 1:
@@ -33,8 +35,10 @@ def _setup_distributed(args):
 
 
 def _sync_all(device, world):
+    if device.type == "cuda":
+        torch.cuda.synchronize()
     if world > 1:
-        if device.type == "cuda":
+        if device.type == "cuda" and dist.get_backend() == "nccl":
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
@@ -45,7 +49,8 @@ def _sync_all(device, world):
 def _max_over_ranks(value: float, device, world) -> float:
     if world == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device if device.type == "cuda" else "cpu")
+    t = torch.tensor([value], dtype=torch.float64,
+                     device=device if (device.type == "cuda" and dist.get_backend() == "nccl") else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

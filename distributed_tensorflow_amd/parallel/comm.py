@@ -20,6 +20,8 @@ import torch.distributed as dist
 def pick_backend(device: torch.device, requested: str = "auto") -> str:
     if requested not in ("auto", "", None):
         return requested
+    if os.environ.get("DTF_DIST_BACKEND"):          # rehearsals: several ranks sharing one GPU cannot use RCCL
+        return os.environ["DTF_DIST_BACKEND"]
     return "nccl" if device.type == "cuda" else "gloo"
 
 

@@ -184,3 +184,26 @@ def test_cli_async_workers_use_the_device_side_engine(monkeypatch):
     gs = sorted([s[1] for s in s0] + [s[1] for s in s1])
     assert gs[-1] >= 60 and len(s0) + len(s1) >= 59            # the two workers share the 60 updates
     assert s0[-1][2] < s0[0][2] - 0.2 and s1[-1][2] < s1[0][2] - 0.2
+
+
+@pytest.mark.parametrize("config,expect", [("mlp_sync", ("peer_mapped_allreduce", True)),
+                                           ("mlp_async", ("engine", "PeerMappedAsyncEngine"))])
+def test_bench_launch_line_with_two_ranks_sharing_the_gpu(config, expect):
+    """The multi-GPU launch line of bench.py (torch.distributed.run, one rank per GPU) rehearsed with two ranks on
+    the one GPU of the test box: gloo carries the process group, the peer-mapped kernels carry the updates."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DTF_DIST_BACKEND="gloo", DTF_SHARE_GPU="1", DTF_P2P_ALLREDUCE="1", DTF_PEER_ASYNC="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "120", "--warmup",
+           "20", "--config", config]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=200, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 prints ONE JSON line, nothing else on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 120 and d["warmup"] == 20 and d["value"] > 0
+    assert d["config"]["global_batch"] == 200 and d["config"][expect[0]] == expect[1]
+    assert abs(d["value"] - 200 * 120 / (d["ms_per_step"] * 120 / 1e3)) < 1e-6 * d["value"]
