@@ -144,7 +144,7 @@ class P2PAllReduce:
 
         params = torch.zeros(n, dtype=torch.float32, device=device)
         try:
-            comm = P2PAllReduce(n, device, group, timeout_s=2.0)      # raises on every rank or on none
+            comm = P2PAllReduce(n, device, group, timeout_s=10.0)     # raises on every rank or on none
         except (RuntimeError, OSError, ValueError):
             good = 0
         if comm is not None:

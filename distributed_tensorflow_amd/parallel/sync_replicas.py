@@ -173,7 +173,9 @@ class SyncReplicasEngine:
     def run(self, n_steps: int, graph_steps: int = 64) -> None:
         """Run ``n_steps`` aggregated updates (each rank contributes as the R/num_workers ratio dictates)."""
         if self.fast:
-            if self.use_coll and not self.capture_collectives:
+            # the peer-mapped update is an ordinary kernel: steps that use it replay from hipGraphs like the
+            # one-rank step; library collectives stay out of captures unless asked for
+            if self.use_coll and not self.capture_collectives and self.p2p is None:
                 self.program.use_graphs = False
             if self.use_coll and self.program.use_graphs:
                 try:
