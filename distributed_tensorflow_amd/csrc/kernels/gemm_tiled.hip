@@ -18,6 +18,8 @@
 // bf16: v_mfma_f32_16x16x32_bf16, fp32 accumulate.  fp32: v_mfma_f32_16x16x4_f32 (exact fp32).
 // Workgroup ids are remapped so that the workgroups sharing an XCD (ids equal mod 8) cover a
 // contiguous band of tiles and share operand panels in that XCD's L2.
+#include <cstdlib>
+
 #include "dtf_kernels.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -53,11 +55,18 @@ __device__ __forceinline__ void mma_slot<unsigned int>(const u32x4& a, const u32
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
 }
 
-template <typename T, int EPI>
+// TI x TJ: MFMA tiles per wave (wave tile 16*TI x 16*TJ); the 2x2 waves of a workgroup cover 32*TI x 32*TJ.
+//   4 x 4: 128x128 block, 64 KB of LDS, two workgroups per CU; per 16 MFMAs a wave reads 8 fragments, which
+//          keeps the LDS port saturated (measured: the loop is LDS-read bound).
+//   8 x 8: 256x256 block, 128 KB of LDS, one workgroup per CU; 16 fragment reads per 64 MFMAs halve the LDS
+//          traffic per flop.  Used for bf16 when the problem fills the chip with such blocks.
+template <typename T, int EPI, int TI, int TJ>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(DtfGemmArgs p) {
   constexpr int PER16 = Elem<T>::PER16;
   constexpr int BKE = 8 * PER16;             // elements per 128-byte LDS row
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][128 * 128];   // [stage][A|B][row*128 + byte]
+  constexpr int BM = 32 * TI, BN = 32 * TJ;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_a[2][BM * 128];   // [stage][row*128 + byte]
+  __shared__ __attribute__((aligned(16))) unsigned char lds_b[2][BN * 128];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(DtfGemmArgs p) {
   const int fr = lane & 15, g = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int wg = dtf_xcd_remap(blockIdx.x, tiles_m * tiles_n);
   // consecutive (remapped) ids walk down a column band of 8 row-tiles: A panels and one B panel stay in L2
   const int band = 8;
@@ -74,106 +83,140 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(DtfGemmArgs p) {
   const int rows_in_band = min(band, tiles_m - b_idx * band);
   const int tm = b_idx * band + in_band % rows_in_band;
   const int tn = in_band / rows_in_band;
-  const int m0 = tm << 7, n0 = tn << 7;
+  const int m0 = tm * BM, n0 = tn * BN;
 
   const rsrc_t ra = make_rsrc(p.A, p.a_bytes), rb = make_rsrc(p.B, p.b_bytes);
 
-  // staging map: 1024 16-byte chunks per operand tile, 4 per thread; chunk = (row, slot)
-  unsigned a_goff[4], b_goff[4];
-  unsigned l_off[4];
+  // staging map: BM*8 (A) and BN*8 (B) 16-byte chunks per stage, TI resp. TJ per thread; chunk = (row, slot)
+  unsigned a_goff[TI], b_goff[TJ];
+  unsigned la_off[TI], lb_off[TJ];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < TI; ++c) {
     const int id = tid + 256 * c;
     const int row = id >> 3, slot = id & 7;
     a_goff[c] = (m0 + row < p.M) ? (unsigned)(m0 + row) * (unsigned)p.lda * (unsigned)sizeof(T) + (unsigned)slot * 16u : kOOB;
+    la_off[c] = (unsigned)row * 128u + (unsigned)((slot ^ (row & 7)) << 4);
+  }
+#pragma unroll
+  for (int c = 0; c < TJ; ++c) {
+    const int id = tid + 256 * c;
+    const int row = id >> 3, slot = id & 7;
     b_goff[c] = (n0 + row < p.N) ? (unsigned)(n0 + row) * (unsigned)p.ldb * (unsigned)sizeof(T) + (unsigned)slot * 16u : kOOB;
-    l_off[c] = (unsigned)row * 128u + (unsigned)((slot ^ (row & 7)) << 4);
+    lb_off[c] = (unsigned)row * 128u + (unsigned)((slot ^ (row & 7)) << 4);
   }
   const int nstage = (p.K + BKE - 1) / BKE;
-  u32x4 ra_reg[4], rb_reg[4];
+  const int my_slot = tid & 7;               // (tid + 256 c) & 7 for every c
+  u32x4 ra_reg[TI], rb_reg[TJ];
   auto stage_load = [&](int t) {
     const int k0 = t * BKE;
+    const bool kin = k0 + my_slot * PER16 < p.K;           // K is a multiple of PER16 (checked by the launcher)
+    const unsigned kb = (unsigned)k0 * (unsigned)sizeof(T);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int slot = (tid + 256 * c) & 7;
-      const bool kin = k0 + slot * PER16 < p.K;           // K is a multiple of PER16 (checked by the launcher)
-      const unsigned kb = (unsigned)k0 * (unsigned)sizeof(T);
+    for (int c = 0; c < TI; ++c)
       ra_reg[c] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)((kin && a_goff[c] != kOOB) ? a_goff[c] + kb : kOOB), 0, 0);
+#pragma unroll
+    for (int c = 0; c < TJ; ++c)
       rb_reg[c] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)((kin && b_goff[c] != kOOB) ? b_goff[c] + kb : kOOB), 0, 0);
-    }
   };
   auto stage_write = [&](int buf) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<u32x4*>(&lds[buf][0][l_off[c]]) = ra_reg[c];
-      *reinterpret_cast<u32x4*>(&lds[buf][1][l_off[c]]) = rb_reg[c];
-    }
+    for (int c = 0; c < TI; ++c) *reinterpret_cast<u32x4*>(&lds_a[buf][la_off[c]]) = ra_reg[c];
+#pragma unroll
+    for (int c = 0; c < TJ; ++c) *reinterpret_cast<u32x4*>(&lds_b[buf][lb_off[c]]) = rb_reg[c];
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bias_grad[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bias_grad[TJ];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) bias_grad[j] = 0.f;
 
   // fragment read offsets: row r = wave base + 16 i + fr, slot s = 4 ks + g  ->  r*128 + ((s ^ (r & 7)) << 4)
-  unsigned a_roff[4], b_roff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a_roff[i] = (unsigned)(wm * 64 + i * 16 + fr) * 128u;
-    b_roff[i] = (unsigned)(wn * 64 + i * 16 + fr) * 128u;
-  }
+  const unsigned a_rbase = (unsigned)(wm * 16 * TI + fr) * 128u, b_rbase = (unsigned)(wn * 16 * TJ + fr) * 128u;
   const int sw = fr & 7;     // (row & 7) == (fr & 7): the row bases are multiples of 16
+
+  auto read_frags = [&](int buf, int ks, u32x4 (&af)[TI], u32x4 (&bf)[TJ]) {
+    const unsigned so = (unsigned)(((4 * ks + g) ^ sw) << 4);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const u32x4*>(&lds_b[buf][b_rbase + (unsigned)j * 2048u + so]);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const u32x4*>(&lds_a[buf][a_rbase + (unsigned)i * 2048u + so]);
+  };
+  auto bias_accumulate = [&](const u32x4 (&bf)[TJ]) {
+    // db[n] = sum_k dY^T[n][k]: each lane adds the 16 bytes it holds of its B rows
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      if (sizeof(T) == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias_grad[j] += bf2f((unsigned short)(bf[j][e] & 0xffff)) + bf2f((unsigned short)(bf[j][e] >> 16));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias_grad[j] += __uint_as_float(bf[j][e]);
+      }
+    }
+  };
 
   stage_load(0);
   stage_write(0);
   __syncthreads();
-  for (int t = 0; t < nstage; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nstage) stage_load(t + 1);
+  if (TI >= 8) {
+    // One wave per SIMD: nothing else hides an LDS read, so the fragments of the second k-step are requested
+    // before the MFMAs of the first (two fragment sets in registers), and the next stage's operands are
+    // written to the other buffer between the two k-steps.
+    u32x4 af0[TI], bf0[TJ], af1[TI], bf1[TJ];
+    for (int t = 0; t < nstage; ++t) {
+      const int cur = t & 1;
+      const bool more = t + 1 < nstage;
+      if (more) stage_load(t + 1);
+      read_frags(cur, 0, af0, bf0);
+      read_frags(cur, 1, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (EPI == EPI_WGRAD) bias_accumulate(bf0);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const unsigned so = (unsigned)(((4 * ks + g) ^ sw) << 4);
-      u32x4 af[4], bf[4];
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *reinterpret_cast<const u32x4*>(&lds[cur][0][a_roff[i] + so]);
-        bf[i] = *reinterpret_cast<const u32x4*>(&lds[cur][1][b_roff[i] + so]);
-      }
-      if (EPI == EPI_WGRAD) {
-        // db[n] = sum_k dY^T[n][k]: each lane adds the 16 bytes it holds of its B rows
+        for (int j = 0; j < TJ; ++j) mma_slot<T>(af0[i], bf0[j], acc[i][j]);
+      if (more) stage_write(cur ^ 1);          // last read a barrier ago
+      if (EPI == EPI_WGRAD) bias_accumulate(bf1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (sizeof(T) == 2) {
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bias_grad[i] += bf2f((unsigned short)(bf[i][e] & 0xffff)) + bf2f((unsigned short)(bf[i][e] >> 16));
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bias_grad[i] += __uint_as_float(bf[i][e]);
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mma_slot<T>(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TJ; ++j) mma_slot<T>(af1[i], bf1[j], acc[i][j]);
+      __syncthreads();
     }
-    if (t + 1 < nstage) stage_write(cur ^ 1);
-    __syncthreads();
+  } else {
+    for (int t = 0; t < nstage; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < nstage) stage_load(t + 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 af[TI], bf[TJ];
+        read_frags(cur, ks, af, bf);
+        if (EPI == EPI_WGRAD) bias_accumulate(bf);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) mma_slot<T>(af[i], bf[j], acc[i][j]);
+      }
+      if (t + 1 < nstage) stage_write(cur ^ 1);
+      __syncthreads();
+    }
   }
 
-  // ---------------- epilogue: acc[i][j][r] = C[m0 + wm*64 + 16i + 4g + r][n0 + wn*64 + 16j + fr]
+  // ---------------- epilogue: acc[i][j][r] = C[m0 + wm*16*TI + 16i + 4g + r][n0 + wn*16*TJ + 16j + fr]
   T* __restrict__ C = static_cast<T*>(p.C);
   T* __restrict__ Ct = static_cast<T*>(p.Ct);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = n0 + wn * 64 + 16 * j + fr;
+  for (int j = 0; j < TJ; ++j) {
+    const int col = n0 + wn * 16 * TJ + 16 * j + fr;
     const bool col_ok = col < p.N;
     const float bias = (EPI == EPI_FWD && p.bias && col_ok) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row0 = m0 + wm * 64 + 16 * i + 4 * g;
+    for (int i = 0; i < TI; ++i) {
+      const int row0 = m0 + wm * 16 * TI + 16 * i + 4 * g;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -224,29 +267,48 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(DtfGemmArgs p) {
     }
   }
   if (EPI == EPI_WGRAD && p.bias_out && tm == 0 && wm == 0) {
-    // lanes fr of the 4 lane groups hold disjoint k ranges of B row (wn*64 + 16i + fr)
+    // lanes fr of the 4 lane groups hold disjoint k ranges of B row (wn*16*TJ + 16i + fr)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TJ; ++i) {
       float s = bias_grad[i];
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
-      const int col = n0 + wn * 64 + 16 * i + fr;
+      const int col = n0 + wn * 16 * TJ + 16 * i + fr;
       if (g == 0 && col < p.N) p.bias_out[col] = s;
     }
   }
 }
 
-template <typename T>
-static int launch_tiled(const DtfGemmArgs& a, hipStream_t s) {
-  const int tiles = dtf_cdiv(a.M, 128) * dtf_cdiv(a.N, 128);
+template <typename T, int TI, int TJ>
+static int launch_tiled_as(const DtfGemmArgs& a, hipStream_t s) {
+  const int tiles = dtf_cdiv(a.M, 32 * TI) * dtf_cdiv(a.N, 32 * TJ);
   dim3 grid(tiles), block(256);
   switch (a.epilogue) {
-    case EPI_FWD: hipLaunchKernelGGL((gemm_tiled_kernel<T, EPI_FWD>), grid, block, 0, s, a); break;
-    case EPI_BWD: hipLaunchKernelGGL((gemm_tiled_kernel<T, EPI_BWD>), grid, block, 0, s, a); break;
-    case EPI_WGRAD: hipLaunchKernelGGL((gemm_tiled_kernel<T, EPI_WGRAD>), grid, block, 0, s, a); break;
+    case EPI_FWD: hipLaunchKernelGGL((gemm_tiled_kernel<T, EPI_FWD, TI, TJ>), grid, block, 0, s, a); break;
+    case EPI_BWD: hipLaunchKernelGGL((gemm_tiled_kernel<T, EPI_BWD, TI, TJ>), grid, block, 0, s, a); break;
+    case EPI_WGRAD: hipLaunchKernelGGL((gemm_tiled_kernel<T, EPI_WGRAD, TI, TJ>), grid, block, 0, s, a); break;
     default: return DTF_ERR_ARG;
   }
   return dtf_check_launch();
+}
+
+static int g_big_tile_mode = -1;      // -1 = by problem size, 0 = never, 1 = always (DTF_GEMM_BIG_TILE)
+
+template <typename T>
+static int launch_tiled(const DtfGemmArgs& a, hipStream_t s) {
+  if (g_big_tile_mode < 0) {
+    const char* e = getenv("DTF_GEMM_BIG_TILE");
+    g_big_tile_mode = e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)) : 2;
+  }
+  // 256x256 blocks pay off once they fill the chip (one block per CU, 256 CUs) and waste little at the edges
+  const long big_tiles = (long)dtf_cdiv(a.M, 256) * dtf_cdiv(a.N, 256);
+  const bool fits = big_tiles >= 192 && (a.M % 256 == 0 || a.M >= 2048) && (a.N % 256 == 0 || a.N >= 2048);
+  // measured at 8192x4096x4096 bf16: forward 714 -> 787, weight gradient 778 -> 901 TFLOP/s; the backward epilogue
+  // (one mask element per output element) is not overlapped by a second resident workgroup any more: 663 -> 587,
+  // so it keeps the 128x128 blocks
+  const bool suited = a.epilogue != EPI_BWD;
+  if (sizeof(T) == 2 && (g_big_tile_mode == 1 || (g_big_tile_mode == 2 && fits && suited))) return launch_tiled_as<T, 8, 8>(a, s);
+  return launch_tiled_as<T, 4, 4>(a, s);
 }
 
 DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s) {
