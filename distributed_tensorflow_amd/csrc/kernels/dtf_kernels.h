@@ -145,6 +145,9 @@ struct DtfGemmArgs {
   int epilogue;
   int dtype;
   unsigned a_bytes, b_bytes;
+  const void* maskT;      // optional transposed mask [N, ldmaskt]: the 4 rows a lane owns are one 8/16-byte load
+  int ldmaskt;
+  int pad_;
 };
 
 // A pre-validated launch sequence: the hand-scheduled step (what a graph partitioner + executor do

@@ -218,15 +218,33 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(DtfGemmArgs p) {
     for (int i = 0; i < TI; ++i) {
       const int row0 = m0 + wm * 16 * TI + 16 * i + 4 * g;
       float v[4];
+      float mk[4] = {1.f, 1.f, 1.f, 1.f};
+      if (EPI == EPI_BWD && col_ok) {
+        if (p.maskT && row0 + 3 < p.M && (p.ldmaskt & 3) == 0) {
+          // the lane's four rows are contiguous in the transposed mask: one load instead of four
+          const T* mt = static_cast<const T*>(p.maskT) + (size_t)col * p.ldmaskt + row0;
+          if (sizeof(T) == 2) {
+            const uint2 q = *reinterpret_cast<const uint2*>(mt);
+            mk[0] = bf2f((unsigned short)(q.x & 0xffff)); mk[1] = bf2f((unsigned short)(q.x >> 16));
+            mk[2] = bf2f((unsigned short)(q.y & 0xffff)); mk[3] = bf2f((unsigned short)(q.y >> 16));
+          } else {
+            const float4 q = *reinterpret_cast<const float4*>(mt);
+            mk[0] = q.x; mk[1] = q.y; mk[2] = q.z; mk[3] = q.w;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (row0 + r < p.M) {
+              const T m = static_cast<const T*>(p.mask)[(size_t)(row0 + r) * p.ldmask + col];
+              mk[r] = sizeof(T) == 2 ? bf2f((unsigned short)m) : __uint_as_float((unsigned)m);
+            }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[i][j][r] + bias;
         if (EPI == EPI_FWD && p.relu) v[r] = fmaxf(v[r], 0.f);
-        if (EPI == EPI_BWD && col_ok && row0 + r < p.M) {
-          const T m = static_cast<const T*>(p.mask)[(size_t)(row0 + r) * p.ldmask + col];
-          const float mf = sizeof(T) == 2 ? bf2f((unsigned short)m) : __uint_as_float((unsigned)m);
-          v[r] = mf > 0.f ? v[r] : 0.f;
-        }
+        if (EPI == EPI_BWD) v[r] = mk[r] > 0.f ? v[r] : 0.f;
       }
       if (!col_ok) continue;
       if (EPI == EPI_WGRAD) {
@@ -306,7 +324,7 @@ static int launch_tiled(const DtfGemmArgs& a, hipStream_t s) {
   // measured at 8192x4096x4096 bf16: forward 714 -> 787, weight gradient 778 -> 901 TFLOP/s; the backward epilogue
   // (one mask element per output element) is not overlapped by a second resident workgroup any more: 663 -> 587,
   // so it keeps the 128x128 blocks
-  const bool suited = a.epilogue != EPI_BWD;
+  const bool suited = a.epilogue != EPI_BWD || a.maskT != nullptr;
   if (sizeof(T) == 2 && (g_big_tile_mode == 1 || (g_big_tile_mode == 2 && fits && suited))) return launch_tiled_as<T, 8, 8>(a, s);
   return launch_tiled_as<T, 4, 4>(a, s);
 }
@@ -325,6 +343,7 @@ DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s) {
   if (((uint64_t)(a->M - 1) * a->lda + a->K) * es > a->a_bytes) return DTF_ERR_SHAPE;
   if (((uint64_t)(a->N - 1) * a->ldb + a->K) * es > a->b_bytes) return DTF_ERR_SHAPE;
   if (a->epilogue == EPI_BWD && (!a->mask || a->ldmask < a->N)) return DTF_ERR_ARG;
+  if (a->maskT && (a->ldmaskt < a->M || !dtf_aligned16(a->maskT))) return DTF_ERR_SHAPE;
   if (a->Ct && a->ldct < a->M) return DTF_ERR_SHAPE;
   if (a->C32 && a->ldc32 < a->N) return DTF_ERR_SHAPE;
   if (a->epilogue == EPI_WGRAD && (a->Ct || a->C32)) return DTF_ERR_ARG;

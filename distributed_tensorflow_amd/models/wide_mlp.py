@@ -95,7 +95,7 @@ class WideMLPProgram(MLPProgram):
         ops.gather_cast_transpose(self.dz[-1], None, self.dzc[-1], self.dzc_t[-1], m=B)
         for l in range(L - 1, 0, -1):
             ops.gemm_nt(self.dzc[l], self._weight(l), self.dzc[l - 1], ops.EPI_BWD, mask=self.h[l - 1],
-                        out_t=self.dzc_t[l - 1], m=B)
+                        mask_t=self.h_t[l - 1], out_t=self.dzc_t[l - 1], m=B)
         for l, name in enumerate(self.names):
             a_t = self.xb_t if l == 0 else self.h_t[l - 1]
             ops.gemm_nt(a_t, self.dzc_t[l], st.grad(f"{name}_w"), ops.EPI_WGRAD, bias_out=st.grad(f"{name}_b"))

@@ -406,11 +406,12 @@ def _dtype_code(t):
 
 
 def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t=None, out_f32=None, bias_out=None,
-            m=None):
+            m=None, mask_t=None):
     """``out[:m] = epilogue(a[:m] @ b^T)`` with ``a`` [M,K] and ``b`` [N,K], both k-contiguous.
 
     forward: ``+bias``, ReLU, optional transposed copy ``out_t`` [N,M] and fp32 copy ``out_f32``;
-    backward: zero where ``mask <= 0``, optional ``out_t``;
+    backward: zero where ``mask <= 0`` (``mask_t``: the same mask transposed, [N, >=M], read with wide loads
+    when given), optional ``out_t``;
     weight gradient: ``out`` is fp32, ``bias_out[n] = sum_k b[n,k]``.
     """
     M = m if m is not None else a.shape[0]
@@ -450,6 +451,9 @@ def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t
         raise ValueError("gemm_nt: out_f32 shape/dtype mismatch")
     if mask is not None and (mask.dtype != a.dtype or mask.shape[0] < M or mask.shape[1] != N):
         raise ValueError("gemm_nt: mask must be [>=M, N] of the operand dtype")
+    if mask_t is not None and (mask is None or mask_t.dtype != a.dtype or mask_t.shape[0] != N or mask_t.shape[1] < M
+                               or mask_t.stride(1) != 1):
+        raise ValueError("gemm_nt: mask_t must be the transposed mask [N, >=M] of the operand dtype")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
         raise ValueError("gemm_nt: bias must be float32 [N]")
     if bias_out is not None and (bias_out.dtype != torch.float32 or bias_out.numel() != N):
@@ -459,7 +463,8 @@ def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t
                          lda=a.stride(0), ldb=b.stride(0), ldc=out.stride(0), ldct=0 if out_t is None else out_t.stride(0),
                          ldc32=0 if out_f32 is None else out_f32.stride(0), ldmask=0 if mask is None else mask.stride(0),
                          relu=int(bool(relu)), epilogue=epilogue, dtype=_dtype_code(a), a_bytes=_lib.span_bytes(a),
-                         b_bytes=_lib.span_bytes(b))
+                         b_bytes=_lib.span_bytes(b), maskT=_lib.ptr(mask_t), ldmaskt=0 if mask_t is None else mask_t.stride(0),
+                         pad_=0)
     _lib.check(_lib.kernels().dtf_gemm_tiled(C.byref(args), _lib.stream_handle()), "gemm_nt")
     return out
 

@@ -63,6 +63,10 @@ def test_backward_and_wgrad_epilogues(dtype):
     rtol, atol = _tol(dtype, OUT)
     _check(dx, want, rtol, atol)
     assert torch.equal(dx_t.float().cpu(), dx.float().cpu().t())
+    # the same product with the mask also given transposed (wide loads in the epilogue)
+    dx2 = torch.zeros(M, IN, dtype=dtype, device=DEV)
+    ops.gemm_nt(dyd, wd, dx2, ops.EPI_BWD, mask=actd, mask_t=actd.t().contiguous())
+    assert torch.equal(dx2.cpu(), dx.cpu())
     # dW[in,out] = X^T dY from the transposed copies; db = column sums of dY
     x_t, dy_t = _rand(IN, M, seed=4).to(DEV, dtype), dyd.t().contiguous()
     dw = torch.zeros(IN, OUT, device=DEV)

@@ -13,10 +13,11 @@ def bench(M, N, K, dtype, epi, reps=20):
     b = (torch.rand(N, K, device=dev) * 2 - 1).to(dtype)
     out = torch.zeros(M, N, dtype=torch.float32 if epi == ops.EPI_WGRAD else dtype, device=dev)
     mask = (torch.rand(M, N, device=dev) - 0.5).to(dtype) if epi == ops.EPI_BWD else None
+    mask_t = mask.t().contiguous() if mask is not None else None
     bias = torch.rand(N, device=dev) if epi == ops.EPI_FWD else None
     out_t = torch.zeros(N, M, dtype=dtype, device=dev) if epi != ops.EPI_WGRAD else None
     bias_out = torch.zeros(N, device=dev) if epi == ops.EPI_WGRAD else None
-    f = lambda: ops.gemm_nt(a, b, out, epi, bias=bias, relu=True, mask=mask, out_t=out_t, bias_out=bias_out)
+    f = lambda: ops.gemm_nt(a, b, out, epi, bias=bias, relu=True, mask=mask, mask_t=mask_t, out_t=out_t, bias_out=bias_out)
     for _ in range(3):
         f()
     torch.cuda.synchronize()
