@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--dtype", default=None)
     ap.add_argument("--no_post_update_accuracy", action="store_true")
     ap.add_argument("--graph_steps", type=int, default=0)
-    ap.add_argument("--collective", default="auto", choices=["auto", "reduce_scatter", "all_reduce"])
+    ap.add_argument("--collective", default="auto", choices=["auto", "reduce_scatter", "all_reduce", "bucketed"])
     ap.add_argument("--cpu", action="store_true", help="run on CPU with gloo (functional check only)")
     ap.add_argument("--force_collectives", action="store_true",
                     help="N=1 only: run the multi-rank code path (gradient store, RCCL collective on a one-rank "

@@ -130,7 +130,7 @@ def bench_resnet50_sync(args, rank, world, device):
     autocast = torch.bfloat16 if dtype_name == "bf16" and device.type == "cuda" else None
     prog = TorchModuleProgram(model, device, images, labels, batch, world_size=world, rank=rank, optimizer=optimizer,
                               lr=1e-3 if optimizer == "adam" else 0.1, autocast=autocast)
-    engine = SyncReplicasEngine(prog, prog.state, collective="reduce_scatter" if world > 1 else "auto")
+    engine = SyncReplicasEngine(prog, prog.state, collective=args.collective)
     _sync_all(device, world)
     engine.run(args.warmup) if args.warmup > 0 else None
     _sync_all(device, world)

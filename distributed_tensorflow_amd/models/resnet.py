@@ -8,7 +8,10 @@ matching flat gradient buffer, and a step is
 
     forward/backward -> reduce-scatter(flat grads) -> fused Adam/SGD on the owned slice -> all-gather
 
-with optimizer state (Adam m, v) existing only for the slice a rank owns.
+with optimizer state (Adam m, v) existing only for the slice a rank owns.  With several ranks the
+flat gradient is aggregated in ~32 MB buckets while autograd is still running: a hook on every
+parameter counts completed gradients per bucket, and complete buckets are handed to the engine
+(``parallel/bucketed.py``) in descending bucket order, the same order on every rank.
 """
 from __future__ import annotations
 
@@ -90,7 +93,8 @@ class TorchModuleProgram:
 
     def __init__(self, module: nn.Module, device, images: torch.Tensor, labels: torch.Tensor, batch: int,
                  world_size: int = 1, rank: int = 0, optimizer: str = "adam", lr: float = 1e-3, gs_inc: int = 1,
-                 autocast: Optional[torch.dtype] = None, channels_last: bool = True, log_capacity: int = 1024):
+                 autocast: Optional[torch.dtype] = None, channels_last: bool = True, log_capacity: int = 1024,
+                 bucket_bytes: Optional[int] = None):
         self.device = torch.device(device)
         self.module = module.to(self.device)
         if channels_last and images.dim() == 4:
@@ -117,13 +121,46 @@ class TorchModuleProgram:
         self.use_graphs = False
         self._graphs = {}
         self.after_compute = None
+        self.grad_ready = None                  # engine hook: called with a bucket index of grad_groups()
+        self._groups = None
+        self.bucket_bytes = bucket_bytes
         self.steps_enqueued = 0
         self.log_cap = log_capacity
         self.log = torch.zeros((log_capacity, 2), dtype=torch.float32, device=self.device)   # loss, correct
         self.gs_log = torch.zeros(log_capacity, dtype=torch.int32, device=self.device)
 
+    def grad_groups(self):
+        """Gradient buckets (consecutive parameters, layout order) and the hooks that report them complete."""
+        if self._groups is None:
+            from ..parallel.bucketed import group_by_bytes
+            self._groups = group_by_bytes(self.state, self.bucket_bytes) if self.bucket_bytes else group_by_bytes(self.state)
+            bucket_of = {n: i for i, g in enumerate(self._groups) for n in g}
+            self._pending = [0] * len(self._groups)
+            self._complete = [False] * len(self._groups)
+            self._next = len(self._groups) - 1
+            for n, p in self.module.named_parameters():
+                p.register_post_accumulate_grad_hook(self._make_hook(bucket_of[n.replace(".", "/")]))
+        return self._groups
+
+    def _make_hook(self, b: int):
+        def hook(_param):
+            if self.grad_ready is None:
+                return
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._complete[b] = True
+                # release in descending order only: the collectives are issued in one order on every rank
+                while self._next >= 0 and self._complete[self._next]:
+                    self.grad_ready(self._next)
+                    self._next -= 1
+        return hook
+
     def enqueue_step(self) -> None:
         s = self.steps_enqueued
+        if self.grad_ready is not None:
+            self._pending = [len(g) for g in self._groups]
+            self._complete = [False] * len(self._groups)
+            self._next = len(self._groups) - 1
         lo = (s * self.B) % max(1, self.n - self.B + 1)
         x, y = self.images[lo:lo + self.B], self.labels[lo:lo + self.B]
         self.state.grads.zero_()

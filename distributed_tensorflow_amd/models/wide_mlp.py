@@ -7,9 +7,13 @@ accumulation and fp32 master weights, or in exact fp32.  Every product is of the
 (``H^T``, ``dZ^T``, ``W^T``) are written by the epilogue of the kernel that produces the tensor.
 
 Per step:  gather+cast batch -> L x forward GEMM (+bias, ReLU) -> head (loss, accuracy, dz)
--> (L-1) x backward GEMM (ReLU mask) -> L x weight-gradient GEMM (+bias gradient) -> small
+-> per layer, top down: weight-gradient GEMM (+bias gradient), backward GEMM (ReLU mask) -> small
 kernel for the 10-class layer -> optimizer / collectives.  The compute copies of the weights are
 rebuilt from the fp32 masters at the start of every step.
+
+A layer's gradients are final as soon as its weight-gradient product has been enqueued; ``grad_ready(l)``
+then lets the engine aggregate that layer's bucket on a second stream while the layers below are still
+being differentiated (``parallel/bucketed.py``).
 """
 from __future__ import annotations
 
@@ -50,7 +54,12 @@ class WideMLPProgram(MLPProgram):
         self.w = [None if T == torch.float32 else z(dims[i], dims[i + 1]) for i in range(len(hidden))]
         self.w_t = [z(dims[i + 1], dims[i]) for i in range(len(hidden))]
         self.refresh_compute_copies()
+        self.grad_ready = None              # engine hook: called with a bucket index of grad_groups()
         del self.schedule_tail_entries      # this program enqueues op by op; the engine then uses after_compute
+
+    def grad_groups(self):
+        """Gradient buckets in layout order: one per hidden layer, then the output layer."""
+        return [[f"{n}_w", f"{n}_b"] for n in self.names] + [["sm_w", "sm_b"]]
 
     def _build_args(self, q: int):
         st = self.state
@@ -93,12 +102,20 @@ class WideMLPProgram(MLPProgram):
                      post_part=self.post_part)
         # dz of the last hidden layer: fp32 from the head -> compute dtype + transposed copy
         ops.gather_cast_transpose(self.dz[-1], None, self.dzc[-1], self.dzc_t[-1], m=B)
-        for l in range(L - 1, 0, -1):
-            ops.gemm_nt(self.dzc[l], self._weight(l), self.dzc[l - 1], ops.EPI_BWD, mask=self.h[l - 1],
-                        mask_t=self.h_t[l - 1], out_t=self.dzc_t[l - 1], m=B)
-        for l, name in enumerate(self.names):
+        # fp32 runs read the master weights in the backward product, which the bucket's all-gather rewrites:
+        # there the bucket is released only after that product has been enqueued
+        early = self.grad_ready is not None and self.w[0] is not None
+        for l in range(L - 1, -1, -1):
             a_t = self.xb_t if l == 0 else self.h_t[l - 1]
-            ops.gemm_nt(a_t, self.dzc_t[l], st.grad(f"{name}_w"), ops.EPI_WGRAD, bias_out=st.grad(f"{name}_b"))
+            ops.gemm_nt(a_t, self.dzc_t[l], st.grad(f"{self.names[l]}_w"), ops.EPI_WGRAD,
+                        bias_out=st.grad(f"{self.names[l]}_b"))
+            if early:
+                self.grad_ready(l)
+            if l > 0:
+                ops.gemm_nt(self.dzc[l], self._weight(l), self.dzc[l - 1], ops.EPI_BWD, mask=self.h[l - 1],
+                            mask_t=self.h_t[l - 1], out_t=self.dzc_t[l - 1], m=B)
+            if self.grad_ready is not None and not early:
+                self.grad_ready(l)
         if self.is_cuda:
             ops.wgrad_grouped(self._args[q]["items"], args=self._args[q]["wgrad"])
         else:
@@ -106,6 +123,8 @@ class WideMLPProgram(MLPProgram):
             ops.wgrad_grouped([ops.WgradItem(self.hact[-1], self.dz2, self.B, n=self.C, dw=st_.grad("sm_w"),
                                              db=st_.grad("sm_b"), w=st_.var("sm_w"), b=st_.var("sm_b"))], lr=None)
             self._tail_cpu(q, init_only=False)
+        if self.grad_ready is not None:
+            self.grad_ready(L)
         if self.after_compute is not None:
             self.after_compute()
         self.steps_enqueued += 1

@@ -36,6 +36,9 @@ from .sharded_state import ShardedState
 # Below this many parameter bytes one all-reduce + replicated SGD beats reduce-scatter + all-gather
 # (two latency-bound collectives instead of one).  Only valid for stateless SGD.
 ALLREDUCE_BELOW_BYTES = 1 << 20
+# From this many parameter bytes on, programs that can signal per-bucket gradient completion overlap the
+# aggregation with their backward pass (parallel/bucketed.py).
+BUCKETED_ABOVE_BYTES = 16 << 20
 
 
 class SyncReplicasEngine:
@@ -64,6 +67,13 @@ class SyncReplicasEngine:
         if collective == "auto":
             small = state.nbytes() < ALLREDUCE_BELOW_BYTES and state.optimizer == "sgd"
             collective = "all_reduce" if small else "reduce_scatter"
+            # large state and a program that reports when parts of its gradient are complete: aggregate bucket by
+            # bucket behind the backward pass (DTF_BUCKETED=0 keeps the single reduce-scatter after it)
+            if (state.nbytes() >= BUCKETED_ABOVE_BYTES and self.use_coll and hasattr(program, "grad_groups")
+                    and os.environ.get("DTF_BUCKETED", "1") != "0"):
+                collective = "bucketed"
+        if collective == "bucketed" and not hasattr(program, "grad_groups"):
+            raise ValueError("collective='bucketed' needs a program that reports gradient buckets (grad_groups)")
         if collective == "all_reduce" and state.optimizer != "sgd":
             raise ValueError("the replicated all-reduce path is only defined for SGD")
         self.collective = collective
@@ -77,6 +87,9 @@ class SyncReplicasEngine:
         if self.world == 1:
             # one rank: R gradients can only come from R successive batches on the same parameters
             self.fast = self.R == 1
+        self.bucketed = None
+        if self.collective == "bucketed" and not (self.fast and not program.fused):
+            self.collective = "reduce_scatter"      # the multi-round path aggregates whole gradients
         if program.gs_inc != (1 if self.fast else 0):
             raise ValueError("program.gs_inc must be 1 on the fast path and 0 when the engine counts updates itself")
         if program.fused and not (self.fast and self.world == 1):
@@ -86,8 +99,29 @@ class SyncReplicasEngine:
         self._update_schedule = None
         if self.fast and not program.fused:
             program.after_compute = self._aggregate_and_apply if self.use_coll else (lambda: state.apply_shard(None, 1.0))
-            if state.device.type == "cuda":
+            if self.collective == "bucketed":
+                self._install_bucketed(group)
+            elif state.device.type == "cuda":
                 self._install_native_update(group)
+
+    def _install_bucketed(self, group) -> None:
+        """Per-bucket reduce-scatter -> optimizer -> all-gather on a side stream, started by the program as each
+        bucket's gradient kernels are enqueued.  On RCCL groups the collectives are issued from the native
+        communicator (C++ on the side stream); otherwise through torch.distributed."""
+        from . import native_comm as nc
+        from .bucketed import BucketedUpdate
+        st, prog = self.state, self.program
+        native = None
+        if (st.device.type == "cuda" and self.use_coll and nc.enabled() and self.coll.backend == "nccl"
+                and group is None):
+            try:
+                native = self.native_comm = nc.NativeComm(self.coll.rank, self.coll.world, st.device)
+            except (RuntimeError, OSError) as e:
+                import warnings
+                warnings.warn(f"native RCCL communicator unavailable ({e}); using torch.distributed collectives")
+        self.bucketed = BucketedUpdate(st, prog.grad_groups(), self.coll, 1.0 / self.R, native)
+        prog.grad_ready = self.bucketed.ready
+        prog.after_compute = self.bucketed.finish
 
     def _install_native_update(self, group) -> None:
         """GPU fast path: aggregation + optimizer + redistribution become ONE entry of the native step

@@ -207,3 +207,48 @@ def test_bench_launch_line_with_two_ranks_sharing_the_gpu(config, expect):
     assert d["n_gpus"] == 2 and d["steps"] == 120 and d["warmup"] == 20 and d["value"] > 0
     assert d["config"]["global_batch"] == 200 and d["config"][expect[0]] == expect[1]
     assert abs(d["value"] - 200 * 120 / (d["ms_per_step"] * 120 / 1e3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_ranks_bucketed_overlap_on_one_gpu(dtype):
+    # buckets are processed on a second stream while the backward kernels of the layers below run;
+    # result must equal the single reduce-scatter after the backward pass, bit for bit
+    from test_bucketed import _wide_rank
+    a = run_ranks(_wide_rank, 2, "bucketed", "adam", "cuda", dtype)
+    b = run_ranks(_wide_rank, 2, "reduce_scatter", "adam", "cuda", dtype)
+    assert (a[0][0] == a[1][0]).all()
+    assert (a[0][0] == b[0][0]).all()
+    assert a[0][1] == 6 and a[0][2][-1] < a[0][2][0]
+
+
+def _bucketed_native_one_rank(rank, world, port, collective):
+    # one-rank RCCL communicator: the native collectives issued on the side stream, events in both directions
+    from distributed_tensorflow_amd import ops
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import build_mlp_state
+    from distributed_tensorflow_amd.models.wide_mlp import WideMLPProgram
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    hidden = [512, 512, 256]
+    ds = mnist.synthetic_data_sets(train_size=2048, validation_size=10, test_size=10, seed=0)
+    st = build_mlp_state(784, hidden, 10, dev, optimizer="adam", lr=1e-3)
+    st.initialize(seed=5)
+    prog = WideMLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=0), 256, hidden, loss_mode=ops.LOSS_STANDARD,
+                          dtype=torch.bfloat16)
+    eng = SyncReplicasEngine(prog, st, collective=collective, force_collectives=True, capture_collectives=False)
+    eng.run(8, 4)
+    torch.cuda.synchronize()
+    out = (st.params.cpu().numpy().copy(), eng.native_comm is not None, eng.bucketed is not None,
+           [r.loss for r in prog.read_log(0, 8)])
+    dist.destroy_process_group()
+    return out
+
+
+def test_bucketed_update_through_native_rccl_entry_points():
+    (a,) = run_ranks(_bucketed_native_one_rank, 1, "bucketed")
+    (b,) = run_ranks(_bucketed_native_one_rank, 1, "reduce_scatter")
+    assert a[1] and a[2] and not b[2]
+    assert (a[0] == b[0]).all()
+    assert a[3][-1] < a[3][0]
