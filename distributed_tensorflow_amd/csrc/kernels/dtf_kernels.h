@@ -229,6 +229,7 @@ struct DtfScheduleEntry {
 DTF_EXPORT int dtf_run_schedule(const DtfScheduleEntry* entries, int n, hipStream_t s);
 
 DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s);
+DTF_EXPORT void dtf_gemm_set_modes(int big_tile, int pingpong);
 DTF_EXPORT int dtf_gather_cast_transpose(const float* src, const int* rows, void* dst, void* dstT, int M, int N, int lds_,
                                          int ldd, int ldt, int dtype, hipStream_t s);
 DTF_EXPORT int dtf_small_gemm(const DtfSmallGemmArgs* a, hipStream_t s);

@@ -1,0 +1,279 @@
+// bf16 GEMM  C[M,N] = A[M,K] . B[N,K]^T  for the large aligned products of the wide layers
+// (M, N multiples of 256, K a multiple of 128): 256x256 block, 8 waves in two groups that alternate on the
+// SIMDs ("ping-pong"): while one group issues its MFMAs, the other issues fragment reads and staging loads.
+//
+// Layout of the work
+//   * 8 waves = 2 (rows) x 4 (columns); a wave owns a 128x64 block of C = 8x4 MFMA tiles of 16x16, held as four
+//     quadrants (ha, hb) of 64x32.  Waves w and w+4 (the two row groups) share a SIMD.
+//   * A K-tile is 64 deep and lives in LDS as four half-tiles of 128 rows x 128 bytes: A0/A1 hold, for both
+//     wave rows, the first/second 64 rows of the wave's 128; B0/B1 hold, for all four wave columns, the
+//     first/second 32 columns of the wave's 64.  Two K-tile buffers: 2 x 4 x 16 KB = 128 KB, one array.
+//   * Staging is direct to LDS (buffer_load ... lds, 16 bytes per lane, no VGPR destination).  One
+//     wave-instruction fills 8 consecutive 128-byte rows; the LDS image is lane-linear, so the XOR swizzle
+//     (16-byte slot ^ (row & 7), which makes the ds_read_b128 fragment reads conflict-free) is applied on the
+//     SOURCE address: the lane that fills physical slot s of row r fetches k-chunk s ^ (r & 7).
+//
+// Schedule: a K-tile takes 4 phases, one quadrant (16 MFMAs = 64x32 x K 64) each, in the order
+//   (0,0) (0,1) (1,1) (1,0), so that a phase reads at most one new operand half:
+//     phase 1: read B0 (4 x ds_read_b128) and A0 (8)     phase 2: read B1 (4)
+//     phase 3: read A1 (8)                               phase 4: nothing (B0 is kept in registers)
+//   and every phase stages ONE half-tile (2 loads per lane) of a later K-tile:
+//     phases 1..8 of an iteration (K-tiles E = 2it in buffer 0, O = 2it+1 in buffer 1) stage
+//       B1(O) A1(O) A0(E+2) B0(E+2) B1(E+2) A1(E+2) A0(O+2) B0(O+2).
+//   Each phase is   reads ; stage ; s_waitcnt vmcnt(8) ; barrier ; 16 MFMAs ; barrier.
+//   The second wave group executes one barrier more at the start, so it runs half a phase behind the first:
+//   its MFMAs coincide with the first group's reads/staging and vice versa.
+//
+// Why the schedule is race-free (phases counted continuously, p):
+//   * vmcnt(8) after the stage of phase p leaves the stages of phases p-3..p outstanding, i.e. the half-tile
+//     staged in phase s has landed, for the waiting wave, in phase s+4; it is read in phase s+5 or later.  Between
+//     that wait and any read lies a barrier that every wave of BOTH groups has passed after its own wait (the late
+//     group waits half a phase later, still before the first group's reads of the next phase).
+//   * a half-tile region is overwritten two or more phases after the last phase that read it (A0: read 1,
+//     restaged 3; B0: 1 -> 4; B1: 2 -> 5; A1: 3 -> 6, same +4 for the odd buffer), so the late group's reads, issued
+//     half a phase after the early group's, have returned (the compiler waits for them before the MFMAs that follow
+//     the next barrier) before any wave issues the overwriting load.
+//   * stages past the last K-tile are issued with an out-of-range offset (the buffer range check drops them), which
+//     keeps the counting uniform; vmcnt(0) before the epilogue: no load may land after the workgroup has ended.
+#include <cstdlib>
+
+#include "dtf_kernels.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+static constexpr unsigned kOOB = 0xFFFFFFF0u;
+
+enum { EPI_FWD = 0, EPI_BWD = 1, EPI_WGRAD = 2 };
+enum { REG_A0 = 0, REG_A1 = 1, REG_B0 = 2, REG_B1 = 3 };
+
+__device__ __forceinline__ unsigned short pp_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ float pp_bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 4 * 16384];   // [buffer][A0 A1 B0 B1][128 rows x 128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, g = lane >> 4;
+
+  const int tiles_n = p.N >> 8, tiles_m = p.M >> 8;
+  const int wg = dtf_xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  // consecutive (remapped) ids walk down a band of 8 row-tiles: the A panels and one B panel stay in that XCD's L2
+  const int band = 8;
+  const int per_band = band * tiles_n;
+  const int b_idx = wg / per_band, in_band = wg % per_band;
+  const int rows_in_band = min(band, tiles_m - b_idx * band);
+  const int tm = b_idx * band + in_band % rows_in_band;
+  const int tn = in_band / rows_in_band;
+  const int m0 = tm << 8, n0 = tn << 8;
+
+  const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)p.b_bytes, 0x00020000);
+
+  // ---- staging sources.  Instruction j (0,1) of this wave fills local rows (8j + wave)*8 .. +7 of a half-tile.
+  //   A half h: local row lr <-> block row (lr >> 6)*128 + h*64 + (lr & 63);  here lr >> 6 == j, lr & 63 == wave*8 + srow
+  //   B half h: local row lr <-> block col (lr >> 5)*64 + h*32 + (lr & 31);   here lr >> 5 == 2j + (wave >> 2)
+  const int srow = lane >> 3;
+  const unsigned kchunk = (unsigned)((lane & 7) ^ srow) * 16u;
+  unsigned a_vo[2], b_vo[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    a_vo[j] = (unsigned)(m0 + j * 128 + wave * 8 + srow) * (unsigned)p.lda * 2u + kchunk;
+    b_vo[j] = (unsigned)(n0 + (2 * j + (wave >> 2)) * 64 + (wave & 3) * 8 + srow) * (unsigned)p.ldb * 2u + kchunk;
+  }
+  const unsigned a_half = 64u * (unsigned)p.lda * 2u, b_half = 32u * (unsigned)p.ldb * 2u;
+  const int nk = p.K >> 6;
+  lds_byte_t* const lds3 = (lds_byte_t*)(lds) + wave * 1024;
+
+  auto stage = [&](int buf, int region, int kt) {
+    const bool live = kt < nk;                       // wave-uniform
+    const unsigned half = (unsigned)(region & 1);
+    const unsigned so = (unsigned)kt * 128u + half * (region < REG_B0 ? a_half : b_half);
+    lds_byte_t* dst = lds3 + buf * 65536 + region * 16384;
+    if (region < REG_B0) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, (int)(live ? a_vo[0] : kOOB), (int)so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst + 8192, 16, (int)(live ? a_vo[1] : kOOB), (int)so, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, (int)(live ? b_vo[0] : kOOB), (int)so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + 8192, 16, (int)(live ? b_vo[1] : kOOB), (int)so, 0, 0);
+    }
+  };
+
+  // ---- fragment reads: A tile i of half ha: local row wr*64 + 16i + fr; B tile jn of half hb: wc*32 + 16jn + fr;
+  //      k-step ks: logical slot 4ks + g, physical slot ^ (fr & 7); the two k-steps differ by byte-offset bit 6
+  const unsigned sw = (unsigned)(fr & 7);
+  const unsigned a_l0 = (unsigned)(wr * 64 + fr) * 128u + (((unsigned)g ^ sw) << 4);
+  const unsigned b_l0 = (unsigned)(wc * 32 + fr) * 128u + (((unsigned)g ^ sw) << 4);
+  const unsigned a_l1 = a_l0 ^ 64u, b_l1 = b_l0 ^ 64u;
+
+  f32x4 acc[2][4][2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bias_grad[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  const bool want_bias = EPI == EPI_WGRAD && p.bias_out != nullptr && tm == 0 && wr == 0;   // wave-uniform
+
+  u32x4 af[4][2], bq0[2][2], bq1[2][2];
+
+#define PP_READ_A(BUF, HA)                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+    af[i][0] = *reinterpret_cast<const u32x4*>(&lds[(BUF) * 65536 + (HA) * 16384 + i * 2048 + a_l0]);   \
+    af[i][1] = *reinterpret_cast<const u32x4*>(&lds[(BUF) * 65536 + (HA) * 16384 + i * 2048 + a_l1]);   \
+  }
+#define PP_READ_B(BUF, HB, BQ)                                                                          \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                       \
+    BQ[j][0] = *reinterpret_cast<const u32x4*>(&lds[(BUF) * 65536 + (HB) * 16384 + j * 2048 + b_l0]);   \
+    BQ[j][1] = *reinterpret_cast<const u32x4*>(&lds[(BUF) * 65536 + (HB) * 16384 + j * 2048 + b_l1]);   \
+  }
+#define PP_BIAS(HB, BQ)                                                                                 \
+  if (want_bias) {                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                    \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                       \
+      bias_grad[HB][j] += pp_bf2f((unsigned short)(BQ[j][ks][e] & 0xffff)) + pp_bf2f((unsigned short)(BQ[j][ks][e] >> 16)); \
+  }
+#define PP_MMA(HA, HB, BQ)                                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+    acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i][ks]), \
+                                                                 __builtin_bit_cast(bf16x8_t, BQ[j][ks]), acc[HA][i][HB][j], 0, 0, 0);
+// one phase: READS ; stage ; counted wait ; barrier ; MFMAs ; barrier
+#define PP_PHASE(READS, ST_BUF, ST_REG, ST_KT, HA, HB, BQ, BIAS)                                        \
+  READS                                                                                                 \
+  stage(ST_BUF, ST_REG, ST_KT);                                                                         \
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  __builtin_amdgcn_s_barrier();                                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  __builtin_amdgcn_s_setprio(1);                                                                        \
+  PP_MMA(HA, HB, BQ)                                                                                    \
+  __builtin_amdgcn_s_setprio(0);                                                                        \
+  BIAS                                                                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  __builtin_amdgcn_s_barrier();                                                                         \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- prologue: what the steady state has in flight at the start of an iteration
+  stage(0, REG_A0, 0); stage(0, REG_B0, 0); stage(0, REG_B1, 0); stage(0, REG_A1, 0);
+  stage(1, REG_A0, 1); stage(1, REG_B0, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();          // this group now runs half a phase behind the other
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int kt = 0; kt < nk; kt += 2) {
+    PP_PHASE(PP_READ_B(0, REG_B0, bq0) __builtin_amdgcn_sched_barrier(0); PP_READ_A(0, REG_A0),
+             1, REG_B1, kt + 1, 0, 0, bq0, PP_BIAS(0, bq0))
+    PP_PHASE(PP_READ_B(0, REG_B1, bq1), 1, REG_A1, kt + 1, 0, 1, bq1, PP_BIAS(1, bq1))
+    PP_PHASE(PP_READ_A(0, REG_A1), 0, REG_A0, kt + 2, 1, 1, bq1, )
+    PP_PHASE(, 0, REG_B0, kt + 2, 1, 0, bq0, )
+    PP_PHASE(PP_READ_B(1, REG_B0, bq0) __builtin_amdgcn_sched_barrier(0); PP_READ_A(1, REG_A0),
+             0, REG_B1, kt + 2, 0, 0, bq0, PP_BIAS(0, bq0))
+    PP_PHASE(PP_READ_B(1, REG_B1, bq1), 0, REG_A1, kt + 2, 0, 1, bq1, PP_BIAS(1, bq1))
+    PP_PHASE(PP_READ_A(1, REG_A1), 1, REG_A0, kt + 3, 1, 1, bq1, )
+    PP_PHASE(, 1, REG_B0, kt + 3, 1, 0, bq0, )
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing may land in LDS after this workgroup has ended
+  if (wr == 0) __builtin_amdgcn_s_barrier();          // same number of barriers in both groups
+#undef PP_PHASE
+#undef PP_MMA
+#undef PP_BIAS
+#undef PP_READ_A
+#undef PP_READ_B
+
+  // ---- epilogue: acc[ha][i][hb][j][r] = C[m0 + wr*128 + ha*64 + 16i + 4g + r][n0 + wc*64 + hb*32 + 16j + fr]
+  typedef unsigned short T;
+  T* __restrict__ C = static_cast<T*>(p.C);
+  T* __restrict__ Ct = static_cast<T*>(p.Ct);
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + hb * 32 + 16 * j + fr;
+      const float bias = (EPI == EPI_FWD && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row0 = m0 + wr * 128 + ha * 64 + 16 * i + 4 * g;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[ha][i][hb][j][r] + bias;
+          if (EPI == EPI_FWD && p.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (EPI == EPI_BWD) {
+            // the lane's four rows are contiguous in the transposed mask
+            const uint2 q = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.maskT) + (size_t)col * p.ldmaskt + row0);
+            const float mk[4] = {pp_bf2f((unsigned short)(q.x & 0xffff)), pp_bf2f((unsigned short)(q.x >> 16)),
+                                 pp_bf2f((unsigned short)(q.y & 0xffff)), pp_bf2f((unsigned short)(q.y >> 16))};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+          }
+          if (EPI == EPI_WGRAD) {
+            float* __restrict__ Cf = static_cast<float*>(p.C);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cf[(size_t)(row0 + r) * p.ldc + col] = v[r];
+            continue;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            C[(size_t)(row0 + r) * p.ldc + col] = pp_f2bf(v[r]);
+            if (p.C32) p.C32[(size_t)(row0 + r) * p.ldc32 + col] = v[r];
+          }
+          if (Ct) {
+            uint2 pk;
+            pk.x = (unsigned)pp_f2bf(v[0]) | ((unsigned)pp_f2bf(v[1]) << 16);
+            pk.y = (unsigned)pp_f2bf(v[2]) | ((unsigned)pp_f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(&Ct[(size_t)col * p.ldct + row0]) = pk;
+          }
+        }
+    }
+  if (want_bias) {
+    // lanes fr of the 4 lane groups hold disjoint k ranges of B row wc*64 + hb*32 + 16j + fr
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float s = bias_grad[hb][j];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (g == 0) p.bias_out[n0 + wc * 64 + hb * 32 + 16 * j + fr] = s;
+      }
+  }
+}
+
+// Shapes this kernel takes: bf16, M and N multiples of 256, K a multiple of 128 (two K-tiles per iteration),
+// the transposed mask for the backward epilogue, 8-byte aligned transposed outputs.
+bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a) {
+  if (a.dtype != 1 || (a.M & 255) || (a.N & 255) || (a.K & 127) || a.K < 256) return false;
+  if (a.epilogue == EPI_BWD && (!a.maskT || (a.ldmaskt & 3))) return false;
+  if (a.Ct && ((a.ldct & 3) || (reinterpret_cast<uintptr_t>(a.Ct) & 7))) return false;
+  if (a.maskT && (reinterpret_cast<uintptr_t>(a.maskT) & 7)) return false;
+  return true;
+}
+
+int dtf_gemm_pingpong_launch(const DtfGemmArgs& a, hipStream_t s) {
+  if (!dtf_gemm_pingpong_takes(a)) return DTF_ERR_SHAPE;
+  dim3 grid((a.M >> 8) * (a.N >> 8)), block(512);
+  switch (a.epilogue) {
+    case EPI_FWD: hipLaunchKernelGGL(gemm_pp_kernel<EPI_FWD>, grid, block, 0, s, a); break;
+    case EPI_BWD: hipLaunchKernelGGL(gemm_pp_kernel<EPI_BWD>, grid, block, 0, s, a); break;
+    case EPI_WGRAD: hipLaunchKernelGGL(gemm_pp_kernel<EPI_WGRAD>, grid, block, 0, s, a); break;
+    default: return DTF_ERR_ARG;
+  }
+  return dtf_check_launch();
+}

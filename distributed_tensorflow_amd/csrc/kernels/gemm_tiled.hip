@@ -310,6 +310,11 @@ static int launch_tiled_as(const DtfGemmArgs& a, hipStream_t s) {
   return dtf_check_launch();
 }
 
+// gemm_pingpong.hip: 8-wave 256x256 kernel for large aligned bf16 products
+bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a);
+int dtf_gemm_pingpong_launch(const DtfGemmArgs& a, hipStream_t s);
+static int g_pingpong_mode = -1;      // -1 = unread, 0 = never, 1 = whenever the shape allows, 2 = by problem size (DTF_GEMM_PINGPONG)
+
 static int g_big_tile_mode = -1;      // -1 = by problem size, 0 = never, 1 = always (DTF_GEMM_BIG_TILE)
 
 template <typename T>
@@ -325,8 +330,21 @@ static int launch_tiled(const DtfGemmArgs& a, hipStream_t s) {
   // (one mask element per output element) is not overlapped by a second resident workgroup any more: 663 -> 587,
   // so it keeps the 128x128 blocks
   const bool suited = a.epilogue != EPI_BWD || a.maskT != nullptr;
+  if (g_pingpong_mode < 0) {
+    const char* e = getenv("DTF_GEMM_PINGPONG");
+    g_pingpong_mode = e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)) : 2;
+  }
+  if (sizeof(T) == 2 && g_pingpong_mode && dtf_gemm_pingpong_takes(a) && (g_pingpong_mode == 1 || big_tiles >= 192))
+    return dtf_gemm_pingpong_launch(a, s);
   if (sizeof(T) == 2 && (g_big_tile_mode == 1 || (g_big_tile_mode == 2 && fits && suited))) return launch_tiled_as<T, 8, 8>(a, s);
   return launch_tiled_as<T, 4, 4>(a, s);
+}
+
+// Kernel selection for tests and tools: 0 = never, 1 = whenever the shape allows, 2 = by problem size, -1 = leave as is
+// (the defaults come from DTF_GEMM_BIG_TILE / DTF_GEMM_PINGPONG, read on first use).
+DTF_EXPORT void dtf_gemm_set_modes(int big_tile, int pingpong) {
+  if (big_tile >= 0) g_big_tile_mode = big_tile;
+  if (pingpong >= 0) g_pingpong_mode = pingpong;
 }
 
 DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s) {

@@ -469,6 +469,16 @@ def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t
     return out
 
 
+def gemm_set_modes(big_tile: int = -1, pingpong: int = -1) -> None:
+    """Kernel selection of ``gemm_nt`` (tests, benchmarks): 0 = never, 1 = whenever the shape allows,
+    2 = by problem size, -1 = unchanged.  ``big_tile``: 256x256 blocks with 4 waves; ``pingpong``: the 8-wave
+    256x256 kernel with direct-to-LDS staging (``csrc/kernels/gemm_pingpong.hip``)."""
+    lib = _lib.kernels()
+    lib.dtf_gemm_set_modes.restype = None
+    lib.dtf_gemm_set_modes.argtypes = [_lib.C.c_int, _lib.C.c_int]
+    lib.dtf_gemm_set_modes(big_tile, pingpong)
+
+
 def gather_cast_transpose(src, rows, dst=None, dst_t=None, m=None):
     """``dst[i] = src[rows[i]]`` (cast to dst's dtype) and ``dst_t = dst^T``; the batch gather of the wide pipeline."""
     M = m if m is not None else (rows.numel() if rows is not None else src.shape[0])

@@ -104,3 +104,59 @@ def test_rejects_unaligned_k():
     a = torch.zeros(16, 10, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError):
         ops.gemm_nt(a, a, torch.zeros(16, 16, dtype=torch.bfloat16, device=DEV))
+
+
+@pytest.fixture
+def pingpong_kernel():
+    ops.gemm_set_modes(pingpong=1)          # take the 8-wave kernel whenever the shape allows
+    yield
+    ops.gemm_set_modes(pingpong=2)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 768, 384), (768, 256, 1024), (256, 1024, 128 * 7)])
+def test_pingpong_kernel_all_epilogues(pingpong_kernel, M, N, K):
+    """The 8-wave direct-to-LDS kernel against fp32 statements; operands asymmetric so that a swapped tile, half
+    or k-chunk anywhere in the staging/fragment maps shows."""
+    dtype = torch.bfloat16
+    a, b, bias = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.1), _rand(N, seed=3)
+    ad, bd = a.to(DEV, dtype), b.to(DEV, dtype)
+    prod = ad.float().cpu() @ bd.float().cpu().t()
+    rtol, atol = _tol(dtype, K)
+    # forward
+    out = torch.zeros(M, N, dtype=dtype, device=DEV)
+    out_t = torch.zeros(N, M, dtype=dtype, device=DEV)
+    out32 = torch.zeros(M, N, device=DEV)
+    ops.gemm_nt(ad, bd, out, ops.EPI_FWD, bias=bias.to(DEV), relu=True, out_t=out_t, out_f32=out32)
+    _check(out32, torch.relu(prod + bias), 1e-3, 1e-4)
+    _check(out, torch.relu(prod + bias), rtol, atol)
+    assert torch.equal(out_t.float().cpu(), out.float().cpu().t())
+    # the same product must come out of the 4-wave kernels bit for bit in fp32 (same MFMA, same k order per tile)
+    ops.gemm_set_modes(pingpong=0)
+    ref32 = torch.zeros(M, N, device=DEV)
+    ops.gemm_nt(ad, bd, torch.zeros_like(out), ops.EPI_FWD, bias=bias.to(DEV), relu=True, out_f32=ref32)
+    ops.gemm_set_modes(pingpong=1)
+    assert torch.equal(ref32.cpu(), out32.cpu())
+    # backward with the transposed mask
+    mask = _rand(M, N, seed=4).to(DEV, dtype)
+    dx = torch.zeros(M, N, dtype=dtype, device=DEV)
+    dx_t = torch.zeros(N, M, dtype=dtype, device=DEV)
+    ops.gemm_nt(ad, bd, dx, ops.EPI_BWD, mask=mask, mask_t=mask.t().contiguous(), out_t=dx_t)
+    _check(dx, torch.where(mask.float().cpu() > 0, prod, torch.zeros(M, N)), rtol, atol)
+    assert torch.equal(dx_t.float().cpu(), dx.float().cpu().t())
+    # weight gradient + bias gradient
+    dw = torch.zeros(M, N, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    ops.gemm_nt(ad, bd, dw, ops.EPI_WGRAD, bias_out=db)
+    _check(dw, prod, 2e-3, 1e-4)
+    _check(db, bd.float().cpu().sum(1), 2e-3, 1e-4)
+
+
+def test_pingpong_identity_layout(pingpong_kernel):
+    n = 512
+    eye = torch.eye(n)
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) - 125      # exact in bf16
+    out = torch.zeros(n, n, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(eye.to(DEV, torch.bfloat16), b.to(DEV, torch.bfloat16), out)
+    assert torch.equal(out.float().cpu(), b.t())
+    ops.gemm_nt(b.to(DEV, torch.bfloat16), eye.to(DEV, torch.bfloat16), out)
+    assert torch.equal(out.float().cpu(), b)

@@ -45,6 +45,9 @@ def bench(M, N, K, dtype, epi, reps=20):
           (f"   (torch addmm+relu {ref:8.3f} ms {2.0*M*N*K/ref/1e9:7.1f} TF)" if ref else ""))
 
 
+if len(sys.argv) > 1:
+    ops.gemm_set_modes(pingpong=int(sys.argv[1]))      # 0: 4-wave kernels only, 1/2: 8-wave ping-pong kernel
+    print("pingpong mode", sys.argv[1])
 for dtype in (torch.bfloat16, torch.float32):
     for (M, N, K) in [(8192, 4096, 4096), (1024, 4096, 4096), (8192, 4096, 784)]:
         bench(M, N, K, dtype, ops.EPI_FWD)
