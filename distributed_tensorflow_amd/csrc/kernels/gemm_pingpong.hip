@@ -194,54 +194,121 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
 #undef PP_READ_B
 
   // ---- epilogue: acc[ha][i][hb][j][r] = C[m0 + wr*128 + ha*64 + 16i + 4g + r][n0 + wc*64 + hb*32 + 16j + fr]
+  // After the last barrier no wave reads operands any more, and every wave turns its own 16 KB of LDS into a
+  // transposition buffer for its 128x64 block: the MFMA result layout (a lane holds 4 rows of one column) would
+  // otherwise store 2-byte pieces; from LDS every global store is 16 bytes per lane and whole 128/256-byte runs.
   typedef unsigned short T;
-  T* __restrict__ C = static_cast<T*>(p.C);
-  T* __restrict__ Ct = static_cast<T*>(p.Ct);
+  unsigned char* const wl = lds + wave * 16384;
+  const int crow = m0 + wr * 128, ccol = n0 + wc * 64;          // origin of this wave's block
+  if (EPI == EPI_WGRAD) {
+    float* __restrict__ Cf = static_cast<float*>(p.C);
 #pragma unroll
-  for (int hb = 0; hb < 2; ++hb)
+    for (int ha = 0; ha < 2; ++ha) {
+      // fp32 image of 64 rows x 64 columns: row R = 16i + 4g + r, 16-byte chunk (c >> 2) ^ ((R >> 2) & 15)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 64 + hb * 32 + 16 * j + fr;
-      const float bias = (EPI == EPI_FWD && p.bias) ? p.bias[col] : 0.f;
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int ha = 0; ha < 2; ++ha)
+        for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row0 = m0 + wr * 128 + ha * 64 + 16 * i + 4 * g;
-          float v[4];
+          for (int j = 0; j < 2; ++j) {
+            const int c = hb * 32 + 16 * j + fr;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[ha][i][hb][j][r] + bias;
-          if (EPI == EPI_FWD && p.relu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-          }
-          if (EPI == EPI_BWD) {
-            // the lane's four rows are contiguous in the transposed mask
-            const uint2 q = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.maskT) + (size_t)col * p.ldmaskt + row0);
-            const float mk[4] = {pp_bf2f((unsigned short)(q.x & 0xffff)), pp_bf2f((unsigned short)(q.x >> 16)),
-                                 pp_bf2f((unsigned short)(q.y & 0xffff)), pp_bf2f((unsigned short)(q.y >> 16))};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
-          }
-          if (EPI == EPI_WGRAD) {
-            float* __restrict__ Cf = static_cast<float*>(p.C);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cf[(size_t)(row0 + r) * p.ldc + col] = v[r];
-            continue;
+            for (int r = 0; r < 4; ++r) {
+              const int R = 16 * i + 4 * g + r;
+              *reinterpret_cast<float*>(&wl[R * 256 + ((((c >> 2) ^ (R >> 2)) & 15) << 4) + (c & 3) * 4]) = acc[ha][i][hb][j][r];
+            }
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            C[(size_t)(row0 + r) * p.ldc + col] = pp_f2bf(v[r]);
-            if (p.C32) p.C32[(size_t)(row0 + r) * p.ldc32 + col] = v[r];
-          }
-          if (Ct) {
-            uint2 pk;
-            pk.x = (unsigned)pp_f2bf(v[0]) | ((unsigned)pp_f2bf(v[1]) << 16);
-            pk.y = (unsigned)pp_f2bf(v[2]) | ((unsigned)pp_f2bf(v[3]) << 16);
-            *reinterpret_cast<uint2*>(&Ct[(size_t)col * p.ldct + row0]) = pk;
-          }
-        }
+      for (int it = 0; it < 16; ++it) {
+        const int R = it * 4 + (lane >> 4), q = lane & 15;
+        const float4 v = *reinterpret_cast<const float4*>(&wl[R * 256 + (((q ^ (R >> 2)) & 15) << 4)]);
+        *reinterpret_cast<float4*>(&Cf[(size_t)(crow + ha * 64 + R) * p.ldc + ccol + q * 4]) = v;
+      }
     }
+  } else {
+    T* __restrict__ C = static_cast<T*>(p.C);
+    T* __restrict__ Ct = static_cast<T*>(p.Ct);
+    uint2 pk[2][4][2][2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = ccol + hb * 32 + 16 * j + fr;
+        const float bias = (EPI == EPI_FWD && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row0 = crow + ha * 64 + 16 * i + 4 * g;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ha][i][hb][j][r] + bias;
+            if (EPI == EPI_FWD && p.relu) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (EPI == EPI_BWD) {
+              // the lane's four rows are contiguous in the transposed mask
+              const uint2 q = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.maskT) + (size_t)col * p.ldmaskt + row0);
+              const float mk[4] = {pp_bf2f((unsigned short)(q.x & 0xffff)), pp_bf2f((unsigned short)(q.x >> 16)),
+                                   pp_bf2f((unsigned short)(q.y & 0xffff)), pp_bf2f((unsigned short)(q.y >> 16))};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+            }
+            if (p.C32) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) p.C32[(size_t)(row0 + r) * p.ldc32 + col] = v[r];
+            }
+            pk[ha][i][hb][j].x = (unsigned)pp_f2bf(v[0]) | ((unsigned)pp_f2bf(v[1]) << 16);
+            pk[ha][i][hb][j].y = (unsigned)pp_f2bf(v[2]) | ((unsigned)pp_f2bf(v[3]) << 16);
+          }
+      }
+    if (Ct) {
+      // transposed image [64 columns][128 rows] bf16: column c, 16-byte chunk (rows 8q..8q+7) at q ^ (c & 15)
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int c = hb * 32 + 16 * j + fr, q = ha * 8 + 2 * i + (g >> 1);
+              *reinterpret_cast<uint2*>(&wl[c * 256 + ((q ^ (c & 15)) << 4) + 8 * (g & 1)]) = pk[ha][i][hb][j];
+            }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int c = it * 4 + (lane >> 4), q = lane & 15;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&wl[c * 256 + ((q ^ (c & 15)) << 4)]);
+        *reinterpret_cast<u32x4*>(&Ct[(size_t)(ccol + c) * p.ldct + crow + q * 8]) = v;
+      }
+    }
+    // row-major image [128 rows][64 columns] bf16: row R, 16-byte chunk (columns 8q..8q+7) at q ^ ((R >> 2) & 7)
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = hb * 32 + 16 * j + fr;
+            const uint2 v = pk[ha][i][hb][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int R = ha * 64 + 16 * i + 4 * g + r;
+              const unsigned w32 = r < 2 ? v.x : v.y;
+              *reinterpret_cast<unsigned short*>(&wl[R * 128 + ((((c >> 3) ^ (R >> 2)) & 7) << 4) + (c & 7) * 2]) =
+                  (unsigned short)((r & 1) ? (w32 >> 16) : (w32 & 0xffff));
+            }
+          }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int R = it * 8 + (lane >> 3), q = lane & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(&wl[R * 128 + (((q ^ (R >> 2)) & 7) << 4)]);
+      *reinterpret_cast<u32x4*>(&C[(size_t)(crow + R) * p.ldc + ccol + q * 8]) = v;
+    }
+  }
   if (want_bias) {
     // lanes fr of the 4 lane groups hold disjoint k ranges of B row wc*64 + hb*32 + 16j + fr
 #pragma unroll
@@ -257,11 +324,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
 }
 
 // Shapes this kernel takes: bf16, M and N multiples of 256, K a multiple of 128 (two K-tiles per iteration),
-// the transposed mask for the backward epilogue, 8-byte aligned transposed outputs.
+// the transposed mask for the backward epilogue, outputs that take 16-byte stores.
 bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a) {
   if (a.dtype != 1 || (a.M & 255) || (a.N & 255) || (a.K & 127) || a.K < 256) return false;
   if (a.epilogue == EPI_BWD && (!a.maskT || (a.ldmaskt & 3))) return false;
-  if (a.Ct && ((a.ldct & 3) || (reinterpret_cast<uintptr_t>(a.Ct) & 7))) return false;
+  if ((reinterpret_cast<uintptr_t>(a.C) & 15) || (a.ldc & (a.epilogue == EPI_WGRAD ? 3 : 7))) return false;
+  if (a.Ct && ((a.ldct & 7) || (reinterpret_cast<uintptr_t>(a.Ct) & 15))) return false;
   if (a.maskT && (reinterpret_cast<uintptr_t>(a.maskT) & 7)) return false;
   return true;
 }
