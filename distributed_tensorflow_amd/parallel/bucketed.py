@@ -21,6 +21,9 @@ xGMI sizing: an MI355X has 7 point-to-point links of ~153 GB/s.  A 4096x4096 fp3
 where RCCL's bandwidth plateaus, and the backward + weight-gradient products of the next layer
 (~0.4 ms at batch 4096) cover them.
 
+On ONE rank (no communicator) the same mechanism overlaps the optimizer with the backward pass: the
+memory-bound update of layer l runs on the second stream beside the MFMA-bound products of the layers below.
+
 The same object runs on CPU/gloo (no streams: the bucket is processed inline), which is how the
 multi-rank arithmetic is tested without GPUs.
 """
@@ -105,7 +108,7 @@ class BucketedUpdate:
             self.local.append((off, off + n))
             off += n
         assert off == state.layout.shard_size
-        self.reduced = torch.empty(off, dtype=torch.float32, device=state.device)
+        self.reduced = torch.empty(off, dtype=torch.float32, device=state.device) if coll is not None else None
         self.cuda = state.device.type == "cuda"
         if self.cuda:
             self.side = torch.cuda.Stream(device=state.device)
@@ -116,9 +119,7 @@ class BucketedUpdate:
 
     # ---- collectives on the current stream
     def _reduce_scatter(self, out: torch.Tensor, full: torch.Tensor) -> None:
-        if self.coll is None:
-            out.copy_(full)                         # one rank, no communicator: the bucket is its own sum
-        elif self.native is not None:
+        if self.native is not None:
             self.native.reduce_scatter_sum(out, full)
         else:
             self.coll.reduce_scatter_sum(out, full)
@@ -136,8 +137,11 @@ class BucketedUpdate:
         lo, hi = self.ranges[i]
         olo, ohi = self.own[i]
         llo, lhi = self.local[i]
-        red = self.reduced[llo:lhi]
-        self._reduce_scatter(red, st.grads[lo:hi])
+        if self.coll is None:
+            red = st.grads[lo:hi]                   # one rank without a communicator: the bucket is its own sum
+        else:
+            red = self.reduced[llo:lhi]
+            self._reduce_scatter(red, st.grads[lo:hi])
         p = st.params[olo:ohi]
         if st.optimizer == "sgd":
             ops.sgd_apply(p, red, st.lr, self.scale)

@@ -99,7 +99,11 @@ class SyncReplicasEngine:
         self._update_schedule = None
         if self.fast and not program.fused:
             program.after_compute = self._aggregate_and_apply if self.use_coll else (lambda: state.apply_shard(None, 1.0))
-            if self.collective == "bucketed":
+            # one rank: the optimizer of layer l beside the products of the layers below.  Opt-in: measured 2.83 ms
+            # against 2.73 ms per wide-MLP step, the 8-wave GEMM leaves no registers for a second kernel's waves
+            overlap_local = (not self.use_coll and state.device.type == "cuda" and hasattr(program, "grad_groups")
+                             and state.nbytes() >= BUCKETED_ABOVE_BYTES and os.environ.get("DTF_OVERLAP_UPDATE", "0") == "1")
+            if self.collective == "bucketed" or overlap_local:
                 self._install_bucketed(group)
             elif state.device.type == "cuda":
                 self._install_native_update(group)
@@ -112,7 +116,7 @@ class SyncReplicasEngine:
         from .bucketed import BucketedUpdate
         st, prog = self.state, self.program
         native = None
-        if (st.device.type == "cuda" and self.use_coll and nc.enabled() and self.coll.backend == "nccl"
+        if (st.device.type == "cuda" and self.use_coll and self.coll is not None and nc.enabled() and self.coll.backend == "nccl"
                 and group is None):
             try:
                 native = self.native_comm = nc.NativeComm(self.coll.rank, self.coll.world, st.device)
