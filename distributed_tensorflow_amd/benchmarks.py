@@ -101,7 +101,10 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
         "vs_baseline": None, "dtype": dtype_name if wide else "fp32", "data": "synthetic MNIST-shape (resident in HBM), random-init weights",
         "config": {"model": (f"wide_mlp 784-7x{hidden_units}-10" if wide else f"reference MLP 784-{hidden_units}-10"),
                    "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
-                   "parallelism": f"dp{world} sync_replicas R={world}, ps state sharded over {world} GPU(s)",
+                   "parallelism": (f"dp{world} sync_replicas R={world}, " +
+                                   ("replicated SGD after one all-reduce (stateless optimizer, 318 KB of parameters)"
+                                    if (world > 1 or force) and engine.collective == "all_reduce"
+                                    else f"ps state sharded over {world} GPU(s)")),
                    "optimizer": optimizer, "loss": "reference (softmax applied twice)", "mode": "sync",
                    "collective": engine.collective if (world > 1 or force) else "none",
                    "native_rccl": engine.native_comm is not None,

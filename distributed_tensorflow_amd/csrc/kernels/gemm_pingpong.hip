@@ -1,5 +1,5 @@
 // bf16 GEMM  C[M,N] = A[M,K] . B[N,K]^T  for the large aligned products of the wide layers
-// (M, N multiples of 256, K a multiple of 128): 256x256 block, 8 waves in two groups that alternate on the
+// (M, N multiples of 256, K a multiple of 8): 256x256 block, 8 waves in two groups that alternate on the
 // SIMDs ("ping-pong"): while one group issues its MFMAs, the other issues fragment reads and staging loads.
 //
 // Layout of the work
@@ -33,8 +33,8 @@
 //     restaged 3; B0: 1 -> 4; B1: 2 -> 5; A1: 3 -> 6, same +4 for the odd buffer), so the late group's reads, issued
 //     half a phase after the early group's, have returned (the compiler waits for them before the MFMAs that follow
 //     the next barrier) before any wave issues the overwriting load.
-//   * stages past the last K-tile are issued with an out-of-range offset (the buffer range check drops them), which
-//     keeps the counting uniform; vmcnt(0) before the epilogue: no load may land after the workgroup has ended.
+//   * stages past the last K-tile (and chunks past K inside it) are issued with an out-of-range offset (the buffer
+//     range check delivers zeros), which keeps the counting uniform; vmcnt(0) before the epilogue: no load may land after the workgroup has ended.
 #include <cstdlib>
 
 #include "dtf_kernels.h"
@@ -87,11 +87,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
     b_vo[j] = (unsigned)(n0 + (2 * j + (wave >> 2)) * 64 + (wave & 3) * 8 + srow) * (unsigned)p.ldb * 2u + kchunk;
   }
   const unsigned a_half = 64u * (unsigned)p.lda * 2u, b_half = 32u * (unsigned)p.ldb * 2u;
-  const int nk = p.K >> 6;
+  // K-tiles: an even number that covers K; 16-byte chunks at or past K are requested out of range (the range check
+  // of the buffer load then delivers zeros), so K only has to be a multiple of 8
+  const int nk = ((p.K + 127) >> 7) << 1;
+  const int klim = p.K * 2 - (int)kchunk;            // a lane's chunk of K-tile kt is inside K iff kt*128 < klim
   lds_byte_t* const lds3 = (lds_byte_t*)(lds) + wave * 1024;
 
   auto stage = [&](int buf, int region, int kt) {
-    const bool live = kt < nk;                       // wave-uniform
+    const bool live = kt * 128 < klim;               // also false for every K-tile past the last
     const unsigned half = (unsigned)(region & 1);
     const unsigned so = (unsigned)kt * 128u + half * (region < REG_B0 ? a_half : b_half);
     lds_byte_t* dst = lds3 + buf * 65536 + region * 16384;
@@ -323,10 +326,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
   }
 }
 
-// Shapes this kernel takes: bf16, M and N multiples of 256, K a multiple of 128 (two K-tiles per iteration),
+// Shapes this kernel takes: bf16, M and N multiples of 256, K a multiple of 8 (16-byte chunks) and at least 256,
 // the transposed mask for the backward epilogue, outputs that take 16-byte stores.
 bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a) {
-  if (a.dtype != 1 || (a.M & 255) || (a.N & 255) || (a.K & 127) || a.K < 256) return false;
+  if (a.dtype != 1 || (a.M & 255) || (a.N & 255) || (a.K & 7) || a.K < 256) return false;
   if (a.epilogue == EPI_BWD && (!a.maskT || (a.ldmaskt & 3))) return false;
   if ((reinterpret_cast<uintptr_t>(a.C) & 15) || (a.ldc & (a.epilogue == EPI_WGRAD ? 3 : 7))) return false;
   if (a.Ct && ((a.ldct & 7) || (reinterpret_cast<uintptr_t>(a.Ct) & 15))) return false;
