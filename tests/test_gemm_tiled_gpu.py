@@ -161,3 +161,21 @@ def test_pingpong_identity_layout(pingpong_kernel):
     assert torch.equal(out.float().cpu(), b.t())
     ops.gemm_nt(b.to(DEV, torch.bfloat16), eye.to(DEV, torch.bfloat16), out)
     assert torch.equal(out.float().cpu(), b)
+
+
+def test_pingpong_full_chip_is_bit_identical_to_the_four_wave_kernel(pingpong_kernel):
+    """One block on every CU, long K loop, repeated: a staging race (a fragment read before its half-tile has
+    landed, or a half-tile overwritten while still being read) shows as a mismatch against the register-staged
+    kernel, which accumulates in the same order."""
+    M = N = 4096
+    K = 2048 + 64 * 3 + 8                  # odd number of K-tiles plus a partial one
+    a, b = _rand(M, K, seed=11).to(DEV, torch.bfloat16), _rand(N, K, seed=12, scale=0.1).to(DEV, torch.bfloat16)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_set_modes(pingpong=0)
+    ref = torch.zeros(M, N, device=DEV)
+    ops.gemm_nt(a, b, out, ops.EPI_FWD, out_f32=ref)
+    ops.gemm_set_modes(pingpong=1)
+    for rep in range(6):
+        got = torch.zeros(M, N, device=DEV)
+        ops.gemm_nt(a, b, out, ops.EPI_FWD, out_f32=got)
+        assert torch.equal(got, ref), f"repetition {rep}: {(got != ref).sum().item()} elements differ"
