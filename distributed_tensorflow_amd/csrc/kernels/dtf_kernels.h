@@ -98,6 +98,20 @@ struct DtfHeadArgs {
 // drives both launches.  Per-step buffers rotate over three slots; `q` is the slot of this step.
 #define DTF_WLOG_INTS 64     // ints per record of the wide log: [0] global_step fetched, [1] local step,
                              // [4+rb] loss-sum bits, [20+rb] correct, [36+rb] post-update correct of row block rb
+// Peer exchange inside launch 2 (mode 2; several ranks on one node, see p2p_allreduce.hip): every training
+// workgroup stores its gradient tiles into this rank's exported slot, publishes "workgroup w of step s is
+// complete" into every peer's flag array, waits for the same workgroup of every peer, sums the peers' tiles in
+// rank order (remote reads over xGMI) and applies theta -= lr * sum - no separate all-reduce/update launch.
+#define DTF_MLP2_MAX_WG 128   // training workgroups (dW1 + dW2 blocks) a flag array has room for
+struct DtfMlp2Peer {
+  const float* slot[8];     // this step's flat gradient slot in every rank's region (own rank: the local pointer)
+  int* wgflags[8];          // arrival flags [3 slots][8 ranks][DTF_MLP2_MAX_WG] of every rank's region
+  int* err;                 // set to 1 when a wait ran into its time limit
+  int rank, world;
+  unsigned timeout_ticks;   // of the 100 MHz constant clock
+  int pad_;
+};
+
 struct DtfMlp2Args {
   const float* X;           // [n, In] dataset rows (ldx)
   const float* labels;      // [n, C]
@@ -117,14 +131,17 @@ struct DtfMlp2Args {
   int h_rows;
   int q;                    // slot of this step, 0..2
   int loss_mode;
-  int mode;                 // 0: store gradients, 1: theta -= lr * grad
+  int mode;                 // 0: store gradients, 1: theta -= lr * grad, 2: peer exchange (gradients -> slot, theta -= lr * sum over ranks)
   int log_cap;
   float lr, inv_b;
   unsigned x_bytes;         // bytes addressable from X
   DtfTailArgs tail;         // state, perm, n_train, gs_inc (its log / partial / ridx fields are not used)
+  DtfMlp2Peer peer;         // mode 2 only
 };
 DTF_EXPORT int dtf_mlp2_fwd(const DtfMlp2Args* a, hipStream_t s);
 DTF_EXPORT int dtf_mlp2_bwd(const DtfMlp2Args* a, hipStream_t s);
+// Fills `out` for gradient slot `slot` of a connected peer-mapped communicator (dtf_p2p_create / dtf_p2p_connect).
+DTF_EXPORT int dtf_p2p_mlp2_peer(void* comm, int slot, double timeout_s, DtfMlp2Peer* out);
 
 // C[M,N] = A[M,K] . B[N,K]^T with both operands k-contiguous (see gemm_tiled.hip).
 // dtype: 0 = fp32, 1 = bf16 (fp32 accumulate).  epilogue: 0 forward (+bias, ReLU, optional transposed copy Ct

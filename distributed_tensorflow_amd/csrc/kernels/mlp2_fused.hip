@@ -353,7 +353,8 @@ __device__ __forceinline__ int dz_slot(int c) { return 4 * (c & 3) + (c >> 2); }
 // One weight-gradient tile per wave.  IS2 = false: tiles of dW1 (inputs x hidden), dz1 rebuilt in registers;
 // IS2 = true: tiles of dW2 (hidden x classes).  `tile0` is the first tile of this workgroup within its kind.
 template <int NJ, int NRB, bool IS2>
-__device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0, int Rp, unsigned zbytes, float* dzs) {
+__device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0, int Rp, unsigned zbytes, float* dzs,
+                                                 int wgid, int* peer_timeout) {
   constexpr int CP = 4 * NJ;                        // classes padded to whole MFMA k-steps
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -416,7 +417,12 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     for (int j = 0; j < NJ; ++j)
       wb[j] = bld(rw, (bn_ok && 4 * j + g < C) ? ((unsigned)(n0 + fr) * (unsigned)C + (unsigned)(4 * j + g)) * 4u : kOOB);
   }
-  if (p.mode == 1) {
+  int seq = 0;
+  if (p.mode == 2) {
+    seq = p.ctr_snap[1] + 1;                        // number of this step, the same on every rank
+    if (tid == 0) *peer_timeout = 0;
+  }
+  if (p.mode >= 1) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 4 * g + r;
@@ -436,7 +442,9 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
   M2_STAMP(3, blockIdx.x);
   __syncthreads();
   M2_STAMP(4, blockIdx.x);
-  if (!has_tile) return;
+  // (mode 2: waves without a tile go on to the barriers of the exchange; their loads are out of range, i.e. zero,
+  // and every store below is guarded)
+  if (!has_tile && p.mode != 2) return;
 
   // ---- the tile ----
   float bq[NRB][4];
@@ -474,23 +482,94 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
   M2_STAMP(5, blockIdx.x);
   float* const dWt = IS2 ? p.dW2 : p.dW1;
   float* const dbt = IS2 ? p.db2 : p.db1;
+  float gv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) gv[r] = acc0[r] + acc1[r];
+  if (mt == 0) {  // wave-uniform: this tile also owns the bias gradient of its 16 columns
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+  }
+  const bool b_lane = mt == 0 && g == 0 && bn_ok;
+  if (p.mode == 2) {
+    // ---- exchange with the same workgroup of every peer, then the averaged update ----
+    const int me = p.peer.rank, world = p.peer.world;
+    size_t woff[4];
+    bool wok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 4 * g + r;
+      wok[r] = row < Mo && bn_ok;
+      woff[r] = wok[r] ? (size_t)(dWt - p.peer.slot[me]) + (size_t)row * N + n0 + fr : 0;
+      if (wok[r]) dWt[(size_t)row * N + n0 + fr] = gv[r];
+    }
+    const size_t boff = b_lane ? (size_t)(dbt - p.peer.slot[me]) + n0 + fr : 0;
+    if (b_lane) dbt[n0 + fr] = bsum;
+    // The slots and flags are uncached memory: a store is in memory (not in a cache) once it is acknowledged, so
+    // "acknowledged, then barrier, then flag" publishes the tile.  No system-scope fence: it would write back and
+    // invalidate the whole L2 once per workgroup, under the other workgroups' feet.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < world && tid != me) {
+      __hip_atomic_store(p.peer.wgflags[tid] + ((p.q * 8 + me) * DTF_MLP2_MAX_WG + wgid), seq, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+      int* f = p.peer.wgflags[me] + ((p.q * 8 + tid) * DTF_MLP2_MAX_WG + wgid);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      // step numbers only grow; a wall-clock limit instead of an endless spin
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > p.peer.timeout_ticks) {
+          *peer_timeout = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      // acquire once per workgroup, after the last flag: invalidates (writes nothing back) whatever this CU or
+      // its L2 may hold of the peers' slots, however the peer mapping is cached on the machine at hand
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    if (*peer_timeout) {                            // parameters stay untouched; the host sees the flag
+      if (tid == 0) *p.peer.err = 1;
+      return;
+    }
+    // every rank adds the N tiles in rank order (its own from registers): bit-identical replicas.  Ranks beyond
+    // the group read this rank's slot again, so the loads need no branch; they are not added.
+    float pv[8][4], pb[8];
+    if (world > 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float* src = p.peer.slot[k < world ? k : me];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[k][r] = __builtin_nontemporal_load(src + woff[r]);
+        pb[k] = __builtin_nontemporal_load(src + boff);
+      }
+    }
+    float sv[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < world) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] += k == me ? gv[r] : pv[k][r];
+        sb += k == me ? bsum : pb[k];
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (wok[r]) Wt[(size_t)(m0 + 4 * g + r) * N + n0 + fr] = wold[r] - p.lr * sv[r];
+    if (b_lane) bt[n0 + fr] = bold - p.lr * sb;
+    M2_STAMP(6, blockIdx.x);
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = m0 + 4 * g + r;
     if (row < Mo && bn_ok) {
-      const float gval = acc0[r] + acc1[r];
       const size_t off = (size_t)row * N + n0 + fr;
-      if (p.mode == 1) Wt[off] = wold[r] - p.lr * gval;
-      else dWt[off] = gval;
+      if (p.mode == 1) Wt[off] = wold[r] - p.lr * gv[r];
+      else dWt[off] = gv[r];
     }
   }
-  if (mt == 0) {  // wave-uniform: this tile also owns the bias gradient of its 16 columns
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
-    if (g == 0 && bn_ok) {
-      if (p.mode == 1) bt[n0 + fr] = bold - p.lr * bsum;
-      else dbt[n0 + fr] = bsum;
-    }
+  if (b_lane) {
+    if (p.mode == 1) bt[n0 + fr] = bold - p.lr * bsum;
+    else dbt[n0 + fr] = bsum;
   }
   M2_STAMP(6, blockIdx.x);
 }
@@ -499,14 +578,15 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
 template <int NJ, int NRB>
 __global__ __launch_bounds__(256) void mlp2_bwd_kernel(DtfMlp2Args p) {
   __shared__ float dzs[128 * 20];
+  __shared__ int peer_timeout;
   const int R16 = (p.R + 15) >> 4, Rp = R16 << 4;
   const int NT = (p.Hd + 15) >> 4;
   const int nb1 = (((p.In + 15) >> 4) * NT + 3) >> 2, nb2 = (NT + 3) >> 2;
   const unsigned zbytes = 16u * (unsigned)Rp * 8u * 4u;
   const int b = blockIdx.x;
   if (b < R16) mlp2_stat_block(p, b, Rp, zbytes);
-  else if (b < R16 + nb1) mlp2_train_block<NJ, NRB, false>(p, (b - R16) * 4, Rp, zbytes, dzs);
-  else if (b < R16 + nb1 + nb2) mlp2_train_block<NJ, NRB, true>(p, (b - R16 - nb1) * 4, Rp, zbytes, dzs);
+  else if (b < R16 + nb1) mlp2_train_block<NJ, NRB, false>(p, (b - R16) * 4, Rp, zbytes, dzs, b - R16, &peer_timeout);
+  else if (b < R16 + nb1 + nb2) mlp2_train_block<NJ, NRB, true>(p, (b - R16 - nb1) * 4, Rp, zbytes, dzs, b - R16, &peer_timeout);
   else mlp2_tail_block(p, b - R16 - nb1 - nb2);
 }
 
@@ -514,7 +594,19 @@ static int mlp2_validate(const DtfMlp2Args* a) {
   if (!a || !a->X || !a->labels || !a->Xg || !a->labg || !a->ridx || !a->H || !a->zpart || !a->W2s || !a->ctr_snap || !a->wlog)
     return DTF_ERR_ARG;
   if (!a->W1 || !a->b1 || !a->W2 || !a->b2 || !a->tail.state) return DTF_ERR_ARG;
-  if (a->mode == 0 ? (!a->dW1 || !a->db1 || !a->dW2 || !a->db2) : a->mode != 1) return DTF_ERR_ARG;
+  if (a->mode < 0 || a->mode > 2) return DTF_ERR_ARG;
+  if (a->mode != 1 && (!a->dW1 || !a->db1 || !a->dW2 || !a->db2)) return DTF_ERR_ARG;
+  if (a->mode == 2) {
+    const DtfMlp2Peer& pe = a->peer;
+    if (pe.world < 1 || pe.world > 8 || pe.rank < 0 || pe.rank >= pe.world || !pe.err) return DTF_ERR_ARG;
+    for (int k = 0; k < pe.world; ++k)
+      if (!pe.slot[k] || !pe.wgflags[k]) return DTF_ERR_ARG;
+    // the four gradient tensors must lie in this rank's slot (their offsets address the peers' slots too)
+    const float* base = pe.slot[pe.rank];
+    if (a->dW1 < base || a->db1 < base || a->dW2 < base || a->db2 < base) return DTF_ERR_ARG;
+    const int NTv = dtf_cdiv(a->Hd, 16);
+    if (dtf_cdiv(dtf_cdiv(a->In, 16) * NTv, 4) + dtf_cdiv(NTv, 4) > DTF_MLP2_MAX_WG) return DTF_ERR_SHAPE;
+  }
   if (a->In <= 0 || a->Hd <= 0 || a->Hd > 128 || a->C <= 0 || a->C > 16 || a->B <= 0 || a->B > MLP2_LABG_ROWS) return DTF_ERR_SHAPE;
   if (a->R != a->B && a->R != 2 * a->B) return DTF_ERR_SHAPE;
   if (a->q < 0 || a->q > 2) return DTF_ERR_ARG;

@@ -17,7 +17,9 @@
 //            update kernel of step s finished reading, and this rank's update kernel of step s+2 waits
 //            for those publications, so no reader is ever overtaken.
 //
-// Opt-in (DTF_P2P_ALLREDUCE=1); RCCL (rccl_comm.hip) is the default transport.
+// The region also carries per-workgroup arrival flags [3][8][DTF_MLP2_MAX_WG] for the variant in which the
+// backward launch of the two-launch step does the exchange itself (mlp2_fused.hip, mode 2).
+// Used automatically for multi-rank RCCL groups on one node after a self-check (DTF_P2P_ALLREDUCE=0: RCCL).
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -41,6 +43,8 @@ struct P2PComm {
 
 inline float* slot_of(char* base, int64_t n, int slot) { return reinterpret_cast<float*>(base) + (size_t)slot * n; }
 inline int* flags_of(char* base, int64_t n) { return reinterpret_cast<int*>(base + (size_t)kSlots * n * sizeof(float)); }
+inline int* wgflags_of(char* base, int64_t n) { return flags_of(base, n) + kSlots * kMaxPeers; }
+constexpr size_t kFlagInts = (size_t)kSlots * kMaxPeers * (1 + DTF_MLP2_MAX_WG);
 
 struct P2PKernelArgs {
   const float* data[kMaxPeers];   // slot of every rank (own rank: local pointer)
@@ -101,7 +105,7 @@ DTF_EXPORT void* dtf_p2p_create(int rank, int world, int64_t n_floats, char* han
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
   P2PComm* c = new P2PComm;
   c->rank = rank; c->world = world; c->n = n_floats;
-  c->bytes = (size_t)kSlots * n_floats * sizeof(float) + kSlots * kMaxPeers * sizeof(int);
+  c->bytes = (size_t)kSlots * n_floats * sizeof(float) + kFlagInts * sizeof(int);
   void* p = nullptr;
   if (hipExtMallocWithFlags(&p, c->bytes, hipDeviceMallocUncached) != hipSuccess) { delete c; return nullptr; }
   c->local = static_cast<char*>(p);
@@ -171,6 +175,23 @@ DTF_EXPORT int dtf_p2p_allreduce_sgd(void* comm, int slot, const int* seq_ptr, f
 DTF_EXPORT int dtf_p2p_update(const DtfP2PUpdateArgs* u, hipStream_t s) {
   if (!u) return DTF_ERR_ARG;
   return dtf_p2p_allreduce_sgd(u->comm, u->slot, u->seq_ptr, u->params, u->sum_out, u->scale, u->timeout_s, s);
+}
+
+DTF_EXPORT int dtf_p2p_mlp2_peer(void* comm, int slot, double timeout_s, DtfMlp2Peer* out) {
+  P2PComm* c = static_cast<P2PComm*>(comm);
+  if (!c || !out || slot < 0 || slot >= kSlots) return DTF_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  for (int p = 0; p < c->world; ++p) {
+    if (!c->peer[p]) return DTF_ERR_ARG;      // dtf_p2p_connect has not run
+    out->slot[p] = slot_of(c->peer[p], c->n, slot);
+    out->wgflags[p] = wgflags_of(c->peer[p], c->n);
+  }
+  out->err = c->err;
+  out->rank = c->rank;
+  out->world = c->world;
+  const double ticks = timeout_s * 1e8;
+  out->timeout_ticks = ticks > 4.0e9 ? 4000000000u : (unsigned)ticks;
+  return DTF_OK;
 }
 
 // 1 if any wait of this communicator ran into its time limit (synchronises with the device).

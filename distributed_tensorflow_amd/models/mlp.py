@@ -103,6 +103,7 @@ class MLPProgram:
         self.schedule_tail_entries = []   # appended by the engine: the native update entry of each step
         self.schedule_tail_fn = None      # optional: slot -> extra entries (an update entry that depends on the slot)
         self.grad_slots = None            # optional: one flat gradient buffer per slot (peer-mapped all-reduce)
+        self.peer_exchange = None         # optional: (per-slot Mlp2Peer structs, lr / R): launch 2 exchanges and updates
         self._eval_buf: Dict = {}
         self._args = [self._build_args(q) for q in range(self.P)] if self.is_cuda else None
         self._started = False
@@ -146,8 +147,9 @@ class MLPProgram:
             out["mlp2"] = ops.build_mlp2_args(
                 self.data.images, self.data.labels, self.xg, self.labg, self.ridx, self.hact[0], self.zpart, self.w2_snap,
                 self.ctr_snap, st.var("hid_w"), st.var("hid_b"), st.var("sm_w"), st.var("sm_b"), self.wlog, self.B, self.R,
-                self.loss_mode, q, tail, lr=st.lr if self.fused else None, dw1=g("hid_w"), db1=g("hid_b"), dw2=g("sm_w"),
-                db2=g("sm_b"))
+                self.loss_mode, q, tail, dw1=g("hid_w"), db1=g("hid_b"), dw2=g("sm_w"), db2=g("sm_b"),
+                lr=st.lr if self.fused else (self.peer_exchange[1] if self.peer_exchange is not None else None),
+                peer=self.peer_exchange[0][q] if self.peer_exchange is not None else None)
         return out
 
     def use_gradient_slots(self, slots) -> None:
@@ -158,9 +160,19 @@ class MLPProgram:
         if any(t.numel() != self.state.grads.numel() or t.dtype != torch.float32 for t in slots):
             raise ValueError("gradient slots must match the flat gradient buffer")
         self.grad_slots = list(slots)
+        self.peer_exchange = None
         self._args = [self._build_args(q) for q in range(self.P)]
         self._schedules.clear()
         self._graphs.clear()
+
+    def use_peer_exchange(self, slots, peers, lr_over_r: float) -> None:
+        """Gradient slots as in :meth:`use_gradient_slots`, and the backward launch itself exchanges the tiles with
+        the peers (``peers[q]``: ``Mlp2Peer`` of slot q) and applies ``theta -= lr_over_r * sum over ranks``."""
+        if len(peers) != self.P:
+            raise ValueError("one peer struct per slot")
+        self.use_gradient_slots(slots)
+        self.peer_exchange = (list(peers), float(lr_over_r))
+        self._args = [self._build_args(q) for q in range(self.P)]
 
     def _launch_cached(self, key, build):
         """Argument structs of a launch are built once per (step parity, call site) and reused: the

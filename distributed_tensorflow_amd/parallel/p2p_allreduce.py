@@ -48,6 +48,8 @@ def _lib_k():
         lib.dtf_p2p_allreduce_sgd.restype = C.c_int
         lib.dtf_p2p_allreduce_sgd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_double,
                                               C.c_void_p]
+        lib.dtf_p2p_mlp2_peer.restype = C.c_int
+        lib.dtf_p2p_mlp2_peer.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(_lib.Mlp2Peer)]
         lib.dtf_p2p_error.restype = C.c_int
         lib.dtf_p2p_error.argtypes = [C.c_void_p]
         lib.dtf_p2p_destroy.restype = None
@@ -112,6 +114,13 @@ class P2PAllReduce:
             raise ValueError("p2p all-reduce: params must be the flat float32 buffer the slots were sized for")
         return P2PUpdateArgs(comm=self._comm, params=params.data_ptr(), sum_out=_lib.ptr(sum_out), seq_ptr=seq.data_ptr(),
                              timeout_s=self.timeout_s, scale=float(scale), slot=slot)
+
+    def mlp2_peer(self, slot: int) -> "_lib.Mlp2Peer":
+        """Peers' slot pointers and per-workgroup arrival flags for the two-launch step's own exchange
+        (``csrc/kernels/mlp2_fused.hip``, mode 2): no separate update launch."""
+        out = _lib.Mlp2Peer()
+        _lib.check(_lib_k().dtf_p2p_mlp2_peer(self._comm, slot, self.timeout_s, C.byref(out)), "p2p_mlp2_peer")
+        return out
 
     def allreduce_sgd(self, slot: int, params: torch.Tensor, seq: torch.Tensor, scale: float,
                       sum_out: Optional[torch.Tensor] = None) -> None:

@@ -95,7 +95,8 @@ class SyncReplicasEngine:
         if program.fused and not (self.fast and self.world == 1):
             raise ValueError("a program with the update fused into its epilogue only fits one rank with R == 1")
         self.native_comm = None
-        self.p2p = None                         # peer-mapped one-shot all-reduce (opt-in), else None
+        self.p2p = None                         # peer-mapped one-shot all-reduce, else None
+        self.p2p_fused = False                  # ... done by the backward launch itself (no update launch)
         self._update_schedule = None
         if self.fast and not program.fused:
             program.after_compute = self._aggregate_and_apply if self.use_coll else (lambda: state.apply_shard(None, 1.0))
@@ -187,11 +188,21 @@ class SyncReplicasEngine:
         except RuntimeError as e:                   # collective failure: raised on every rank
             warnings.warn(f"peer-mapped all-reduce unavailable ({e}); using RCCL")
             return False
-        prog.use_gradient_slots(self.p2p.slots)
-        # the step number the update kernel publishes: local_step after the tail's increment (equal on all ranks)
-        seq = st.state[1:2]
-        self._p2p_args = [self.p2p.update_args(q, st.params, seq, st.lr / self.R) for q in range(prog.P)]
-        prog.schedule_tail_fn = lambda q: [(p2p.OP_P2P_UPDATE, self._p2p_args[q], 0)]
+        self.p2p_fused = os.environ.get("DTF_P2P_FUSED", "1") != "0"
+        if os.environ.get("DTF_SHARE_GPU") == "1" and self.world > 3:
+            # rehearsal with several ranks on ONE GPU: the waiting backward launches of the other ranks (108 workgroups
+            # each) would occupy every CU, and a forward workgroup (1024 threads) needs a whole one - a deadlock that
+            # cannot occur with one rank per GPU.  The separate update launch waits with fewer workgroups.
+            self.p2p_fused = False
+        if self.p2p_fused:
+            # the backward launch exchanges gradient tiles with the peers and applies the update: two launches per step
+            prog.use_peer_exchange(self.p2p.slots, [self.p2p.mlp2_peer(q) for q in range(prog.P)], st.lr / self.R)
+        else:
+            prog.use_gradient_slots(self.p2p.slots)
+            # the step number the update kernel publishes: local_step after the tail's increment (equal on all ranks)
+            seq = st.state[1:2]
+            self._p2p_args = [self.p2p.update_args(q, st.params, seq, st.lr / self.R) for q in range(prog.P)]
+            prog.schedule_tail_fn = lambda q: [(p2p.OP_P2P_UPDATE, self._p2p_args[q], 0)]
         prog._schedules.clear()
         prog.after_compute = None
         return True

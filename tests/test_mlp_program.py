@@ -238,7 +238,8 @@ def test_gpu_two_launch_step_matches_three_launch_step(monkeypatch, hidden, batc
 
 
 @pytest.mark.gpu
-def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch, fused):
     """DTF_P2P_ALLREDUCE=1 on a one-rank group: gradients go through the exported slot buffers and the one-shot
     update kernel (captured in the step graph); the trajectory must equal the fused local update."""
     import torch.distributed as dist
@@ -251,6 +252,7 @@ def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch):
 
     def make(p2p):
         monkeypatch.setenv("DTF_P2P_ALLREDUCE", "1" if p2p else "0")
+        monkeypatch.setenv("DTF_P2P_FUSED", fused)
         st = build_mlp_state(784, [100], 10, "cuda", lr=0.3)
         st.initialize(seed=11)
         prog = MLPProgram(st, DeviceDataset(ds.train, "cuda", shuffle_seed=5), 100, [100], fused_update=not p2p)
@@ -262,6 +264,7 @@ def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch):
     st_p, prog_p, eng_p = make(True)
     st_f, prog_f, eng_f = make(False)
     assert eng_p.p2p is not None and prog_p.after_compute is None and eng_f.p2p is None
+    assert eng_p.p2p_fused == (fused == "1")
     for a, b in zip(prog_p.read_log(0, 30), prog_f.read_log(0, 30)):
         assert abs(a.loss - b.loss) < 1e-5 and a.global_step == b.global_step
     torch.testing.assert_close(st_p.params, st_f.params, rtol=1e-5, atol=1e-6)

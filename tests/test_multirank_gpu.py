@@ -12,9 +12,10 @@ from test_cli import COMMON, _finish, _launch, _steps
 pytestmark = pytest.mark.gpu
 
 
-def _sync_gpu(rank, world, port, collective, p2p=False):
+def _sync_gpu(rank, world, port, collective, p2p=False, fused="1"):
     if p2p:
         os.environ["DTF_P2P_ALLREDUCE"] = "1"
+        os.environ["DTF_P2P_FUSED"] = fused
     from distributed_tensorflow_amd.data import mnist
     from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
     from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
@@ -30,7 +31,7 @@ def _sync_gpu(rank, world, port, collective, p2p=False):
     torch.cuda.synchronize()
     recs = prog.read_log(0, 20)
     out = {"params": st.params.cpu().numpy().copy(), "gs": st.global_step(), "first": recs[0].loss, "last": recs[-1].loss,
-           "p2p": eng.p2p is not None}
+           "p2p": eng.p2p is not None, "fused": eng.p2p_fused}
     dist.barrier()
     dist.destroy_process_group()
     return out
@@ -105,12 +106,15 @@ def test_p2p_allreduce_between_processes_sharing_the_gpu(world):
     assert all(r["ok"] for r in res)
 
 
-def test_two_ranks_sync_with_peer_mapped_allreduce():
-    """The whole engine path of the opt-in one-shot all-reduce: self-check, gradients written into the exported
-    slots by the backward launch, one update kernel per step; against the same run over the process group."""
-    a, b = run_ranks(_sync_gpu, 2, "all_reduce", True)
-    c, d = run_ranks(_sync_gpu, 2, "all_reduce", False)
-    assert a["p2p"] and b["p2p"] and not c["p2p"]
+@pytest.mark.parametrize("world,fused", [(2, "1"), (2, "0"), (3, "1")])
+def test_ranks_sync_with_peer_mapped_allreduce(world, fused):
+    """The whole engine path of the one-shot all-reduce: self-check, gradients written into the exported slots by
+    the backward launch, then either the same launch exchanges tiles with the peers and updates (fused) or one
+    update kernel per step does; against the same run over the process group."""
+    res = run_ranks(_sync_gpu, world, "all_reduce", True, fused)
+    a, b = res[0], res[-1]
+    c = run_ranks(_sync_gpu, world, "all_reduce", False)[0]
+    assert a["p2p"] and b["p2p"] and not c["p2p"] and a["fused"] == (fused == "1")
     assert (a["params"] == b["params"]).all()              # replicas stay bit-identical
     assert a["gs"] == b["gs"] == 21
     import numpy as np
