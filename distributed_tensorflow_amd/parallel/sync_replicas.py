@@ -189,13 +189,21 @@ class SyncReplicasEngine:
             warnings.warn(f"peer-mapped all-reduce unavailable ({e}); using RCCL")
             return False
         self.p2p_fused = os.environ.get("DTF_P2P_FUSED", "1") != "0"
+        self._replica_checks_left = 1 if self.world > 1 else 0      # after the first run() (a warm-up, as a rule)
         if os.environ.get("DTF_SHARE_GPU") == "1" and self.world > 3:
             # rehearsal with several ranks on ONE GPU: the waiting backward launches of the other ranks (108 workgroups
             # each) would occupy every CU, and a forward workgroup (1024 threads) needs a whole one - a deadlock that
             # cannot occur with one rank per GPU.  The separate update launch waits with fewer workgroups.
             self.p2p_fused = False
+        self._wire_p2p()
+        return True
+
+    def _wire_p2p(self) -> None:
+        from . import p2p_allreduce as p2p
+        st, prog = self.state, self.program
         if self.p2p_fused:
             # the backward launch exchanges gradient tiles with the peers and applies the update: two launches per step
+            prog.schedule_tail_fn = None
             prog.use_peer_exchange(self.p2p.slots, [self.p2p.mlp2_peer(q) for q in range(prog.P)], st.lr / self.R)
         else:
             prog.use_gradient_slots(self.p2p.slots)
@@ -205,7 +213,31 @@ class SyncReplicasEngine:
             prog.schedule_tail_fn = lambda q: [(p2p.OP_P2P_UPDATE, self._p2p_args[q], 0)]
         prog._schedules.clear()
         prog.after_compute = None
-        return True
+
+    def _check_replicas(self) -> None:
+        """After the first runs over peer-mapped buffers: every rank must hold bit-identical parameters (the kernels
+        add the ranks' gradients in one order everywhere).  A difference means the machine orders the peer traffic
+        differently from what the in-launch exchange assumes: the ranks then take rank 0's parameters and continue
+        with the separate update launch (acquire/release at system scope); a second difference is an error."""
+        if self.p2p is None or self._replica_checks_left <= 0:
+            return
+        self._replica_checks_left -= 1
+        p = self.state.params
+        digest = (float(p.double().sum().item()), float(p.double().square().sum().item()))
+        seen = [None] * self.world
+        dist.all_gather_object(seen, digest, group=self.coll.group)
+        if all(d == seen[0] for d in seen):
+            return
+        import warnings
+        if not self.p2p_fused:
+            raise RuntimeError(f"peer-mapped all-reduce: replicas differ after the update ({seen})")
+        warnings.warn("peer exchange inside the backward launch left the replicas different on this machine; "
+                      "continuing from rank 0's parameters with the separate update launch")
+        self.p2p_fused = False
+        self.coll.broadcast(p, src=0)
+        self._wire_p2p()
+        self._replica_checks_left = 1
+
 
     # ------------------------------------------------------------------ fast path (R == num_workers)
     def _aggregate_and_apply(self) -> None:
@@ -240,6 +272,7 @@ class SyncReplicasEngine:
             self.updates_applied += n_steps
             if self.p2p is not None and self.p2p.timed_out():
                 raise RuntimeError("peer-mapped all-reduce: a peer's gradients did not arrive within the time limit")
+            self._check_replicas()
             return
         for _ in range(n_steps):
             self._general_update()

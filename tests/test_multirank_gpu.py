@@ -289,3 +289,44 @@ def test_module_buckets_released_from_autograd_thread_on_gpu():
     np.testing.assert_allclose(a[0], b[0], rtol=1e-3, atol=1e-4)
     (c,) = run_ranks(_module_bucketed_one_rank, 1, "bucketed", 8)
     assert abs(c[2][0] - a[2][0]) < 1e-4 and c[2][-1] < c[2][0]
+
+
+def _replica_fallback(rank, world, port):
+    os.environ["DTF_P2P_ALLREDUCE"] = "1"
+    os.environ["DTF_P2P_FUSED"] = "1"
+    import warnings
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=100, test_size=300, seed=rank)
+    st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, lr=0.5)
+    st.initialize(seed=3)
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=rank), 100, [100], fused_update=False)
+    eng = SyncReplicasEngine(prog, st, collective="all_reduce")
+    assert eng.p2p is not None and eng.p2p_fused
+    eng.run(6, 4)                                   # first run: replicas compared, equal
+    torch.cuda.synchronize()
+    # what a machine with a different ordering of peer traffic would produce: one replica off
+    if rank == 1:
+        st.params[5] += 1.0
+    eng._replica_checks_left = 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        eng.run(6, 4)
+    torch.cuda.synchronize()
+    warned = any("separate update launch" in str(x.message) for x in w)
+    eng.run(8, 4)                                   # continues on the separate update launch, compared once more
+    torch.cuda.synchronize()
+    out = (st.params.cpu().numpy().copy(), warned, eng.p2p_fused, st.global_step())
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def test_differing_replicas_fall_back_to_the_update_launch():
+    a, b = run_ranks(_replica_fallback, 2)
+    assert a[1] and b[1] and not a[2] and not b[2]
+    assert (a[0] == b[0]).all() and a[3] == b[3] == 21
