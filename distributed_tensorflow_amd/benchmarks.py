@@ -109,6 +109,7 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
                    "collective": engine.collective if (world > 1 or force) else "none",
                    "native_rccl": engine.native_comm is not None,
                    "peer_mapped_allreduce": getattr(engine, "p2p", None) is not None,
+                   "peer_exchange_inside_backward_launch": bool(getattr(engine, "p2p_fused", False)) and getattr(engine, "p2p", None) is not None,
                    "post_update_accuracy_pass": not args.no_post_update_accuracy,
                    "hip_graph": bool(prog.use_graphs), "params": state.layout.used},
         "final_loss": last.loss,
@@ -218,7 +219,8 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
         "config": {"model": (f"wide_mlp 784-7x{hidden_units}-10" if wide else f"reference MLP 784-{hidden_units}-10"),
                    "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
                    "parallelism": f"dp{world} async push/pull, {shards} ps shard(s), staleness {getattr(engine, 'staleness', 0)}",
-                   "optimizer": optimizer, "mode": "async", "engine": type(engine).__name__, "params": state.layout.used},
+                   "optimizer": optimizer, "mode": "async", "engine": type(engine).__name__,
+                   "push_pull_inside_backward_launch": bool(getattr(engine, "fused", False)), "params": state.layout.used},
         "global_step": state.global_step() if rank == 0 else None,
     }
 

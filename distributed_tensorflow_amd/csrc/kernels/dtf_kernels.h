@@ -112,6 +112,19 @@ struct DtfMlp2Peer {
   int pad_;
 };
 
+// Asynchronous push/pull inside launch 2 (mode 3; see the async section of p2p_allreduce.hip): every weight-
+// gradient tile is applied to the owner's master slice through its mapped pointer (read at the start of the
+// launch, written back minus lr * gradient: the lock-free read-modify-write of the reference's async mode) and
+// kept as the local replica; the tail bumps the step counters with system-scope atomics.
+struct DtfMlp2Async {
+  float* master[8];         // master slice of every shard (own shard: local pointer)
+  int* counters[8];         // per shard: [0] global_step (shard 0 only), [1] updates applied to this shard
+  const float* params_base; // start of the local flat parameter buffer (W1, b1, W2, b2 are views into it)
+  long long slice;          // floats per shard
+  int shards;
+  int pad_;
+};
+
 struct DtfMlp2Args {
   const float* X;           // [n, In] dataset rows (ldx)
   const float* labels;      // [n, C]
@@ -131,12 +144,14 @@ struct DtfMlp2Args {
   int h_rows;
   int q;                    // slot of this step, 0..2
   int loss_mode;
-  int mode;                 // 0: store gradients, 1: theta -= lr * grad, 2: peer exchange (gradients -> slot, theta -= lr * sum over ranks)
+  int mode;                 // 0: store gradients, 1: theta -= lr * grad, 2: peer exchange (gradients -> slot, theta -= lr * sum over ranks),
+                            // 3: async push/pull (master -= lr * grad through the mapped slices, replica = master)
   int log_cap;
   float lr, inv_b;
   unsigned x_bytes;         // bytes addressable from X
   DtfTailArgs tail;         // state, perm, n_train, gs_inc (its log / partial / ridx fields are not used)
   DtfMlp2Peer peer;         // mode 2 only
+  DtfMlp2Async async_;      // mode 3 only
 };
 DTF_EXPORT int dtf_mlp2_fwd(const DtfMlp2Args* a, hipStream_t s);
 DTF_EXPORT int dtf_mlp2_bwd(const DtfMlp2Args* a, hipStream_t s);

@@ -255,7 +255,15 @@ __device__ __forceinline__ void mlp2_tail_block(const DtfMlp2Args& p, int tb) {
     int* rec = p.wlog + (size_t)DTF_WLOG_INTS * (ls % p.log_cap);
     rec[0] = gs;       // value of global_step before this step's increment
     rec[1] = ls;
-    t.state[0] = gs + t.gs_inc;
+    if (p.mode == 3) {
+      // the ps-side counters: global_step next to shard 0, one "updates applied" counter per shard
+      const int g2 = __hip_atomic_fetch_add(p.async_.counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
+      for (int s = 0; s < p.async_.shards; ++s)
+        __hip_atomic_fetch_add(p.async_.counters[s] + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      t.state[0] = g2;   // global_step as the ps holds it after this worker's update
+    } else {
+      t.state[0] = gs + t.gs_inc;
+    }
     t.state[1] = ls + 1;
   }
   if (i >= B) return;
@@ -417,12 +425,32 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     for (int j = 0; j < NJ; ++j)
       wb[j] = bld(rw, (bn_ok && 4 * j + g < C) ? ((unsigned)(n0 + fr) * (unsigned)C + (unsigned)(4 * j + g)) * 4u : kOOB);
   }
+  float* mptr[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* mbptr = nullptr;
+  if (p.mode == 3) {
+    // master values of this tile, requested now: the (possibly remote) read overlaps the whole launch
+    const long long slice = p.async_.slice;
+    const long long wbase = (long long)(Wt - p.async_.params_base), bbase = (long long)(bt - p.async_.params_base);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 4 * g + r;
+      const bool ok = row < Mo && bn_ok;
+      const long long idx = ok ? wbase + (long long)row * N + n0 + fr : 0;
+      const int sh = p.async_.shards == 1 ? 0 : (int)(idx / slice);
+      mptr[r] = p.async_.master[sh] + (idx - (long long)sh * slice);
+      wold[r] = __builtin_nontemporal_load(mptr[r]);
+    }
+    const long long bidx = (mt == 0 && g == 0 && bn_ok) ? bbase + n0 + fr : 0;
+    const int bsh = p.async_.shards == 1 ? 0 : (int)(bidx / slice);
+    mbptr = p.async_.master[bsh] + (bidx - (long long)bsh * slice);
+    bold = __builtin_nontemporal_load(mbptr);
+  }
   int seq = 0;
   if (p.mode == 2) {
     seq = p.ctr_snap[1] + 1;                        // number of this step, the same on every rank
     if (tid == 0) *peer_timeout = 0;
   }
-  if (p.mode >= 1) {
+  if (p.mode == 1 || p.mode == 2) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 4 * g + r;
@@ -563,13 +591,27 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     const int row = m0 + 4 * g + r;
     if (row < Mo && bn_ok) {
       const size_t off = (size_t)row * N + n0 + fr;
-      if (p.mode == 1) Wt[off] = wold[r] - p.lr * gv[r];
-      else dWt[off] = gv[r];
+      if (p.mode == 3) {
+        const float w = wold[r] - p.lr * gv[r];
+        __builtin_nontemporal_store(w, mptr[r]);      // push: the master, wherever it lives
+        Wt[off] = w;                                   // pull: the same value is this worker's replica
+      } else if (p.mode == 1) {
+        Wt[off] = wold[r] - p.lr * gv[r];
+      } else {
+        dWt[off] = gv[r];
+      }
     }
   }
   if (b_lane) {
-    if (p.mode == 1) bt[n0 + fr] = bold - p.lr * bsum;
-    else dbt[n0 + fr] = bsum;
+    if (p.mode == 3) {
+      const float w = bold - p.lr * bsum;
+      __builtin_nontemporal_store(w, mbptr);
+      bt[n0 + fr] = w;
+    } else if (p.mode == 1) {
+      bt[n0 + fr] = bold - p.lr * bsum;
+    } else {
+      dbt[n0 + fr] = bsum;
+    }
   }
   M2_STAMP(6, blockIdx.x);
 }
@@ -594,8 +636,19 @@ static int mlp2_validate(const DtfMlp2Args* a) {
   if (!a || !a->X || !a->labels || !a->Xg || !a->labg || !a->ridx || !a->H || !a->zpart || !a->W2s || !a->ctr_snap || !a->wlog)
     return DTF_ERR_ARG;
   if (!a->W1 || !a->b1 || !a->W2 || !a->b2 || !a->tail.state) return DTF_ERR_ARG;
-  if (a->mode < 0 || a->mode > 2) return DTF_ERR_ARG;
-  if (a->mode != 1 && (!a->dW1 || !a->db1 || !a->dW2 || !a->db2)) return DTF_ERR_ARG;
+  if (a->mode < 0 || a->mode > 3) return DTF_ERR_ARG;
+  if ((a->mode == 0 || a->mode == 2) && (!a->dW1 || !a->db1 || !a->dW2 || !a->db2)) return DTF_ERR_ARG;
+  if (a->mode == 3) {
+    const DtfMlp2Async& as = a->async_;
+    if (as.shards < 1 || as.shards > 8 || as.slice <= 0 || !as.params_base) return DTF_ERR_ARG;
+    for (int s = 0; s < as.shards; ++s)
+      if (!as.master[s] || !as.counters[s]) return DTF_ERR_ARG;
+    // the four parameter tensors must be views into the flat buffer the slices partition
+    const float* lo = as.params_base;
+    const float* hi = lo + as.slice * as.shards;
+    if (a->W1 < lo || a->b1 < lo || a->W2 < lo || a->b2 < lo) return DTF_ERR_ARG;
+    if (a->W1 + (size_t)a->In * a->Hd > hi || a->b1 + a->Hd > hi || a->W2 + (size_t)a->Hd * a->C > hi || a->b2 + a->C > hi) return DTF_ERR_SHAPE;
+  }
   if (a->mode == 2) {
     const DtfMlp2Peer& pe = a->peer;
     if (pe.world < 1 || pe.world > 8 || pe.rank < 0 || pe.rank >= pe.world || !pe.err) return DTF_ERR_ARG;

@@ -104,6 +104,7 @@ class MLPProgram:
         self.schedule_tail_fn = None      # optional: slot -> extra entries (an update entry that depends on the slot)
         self.grad_slots = None            # optional: one flat gradient buffer per slot (peer-mapped all-reduce)
         self.peer_exchange = None         # optional: (per-slot Mlp2Peer structs, lr / R): launch 2 exchanges and updates
+        self.async_push = None            # optional: (Mlp2Async, lr): launch 2 applies its gradients to the mapped masters
         self._eval_buf: Dict = {}
         self._args = [self._build_args(q) for q in range(self.P)] if self.is_cuda else None
         self._started = False
@@ -138,7 +139,7 @@ class MLPProgram:
         out = {"head": head, "wgrad": wgrad, "items": items}
         if self.fused2:
             tail = ops.make_tail(st.state, perm=self.data.perm, batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
-            if self.fused:
+            if self.fused or self.async_push is not None:
                 g = lambda n: None
             elif self.grad_slots is not None:
                 g = lambda n: st._view(self.grad_slots[q], n)      # gradients land in this slot's exported buffer
@@ -148,8 +149,10 @@ class MLPProgram:
                 self.data.images, self.data.labels, self.xg, self.labg, self.ridx, self.hact[0], self.zpart, self.w2_snap,
                 self.ctr_snap, st.var("hid_w"), st.var("hid_b"), st.var("sm_w"), st.var("sm_b"), self.wlog, self.B, self.R,
                 self.loss_mode, q, tail, dw1=g("hid_w"), db1=g("hid_b"), dw2=g("sm_w"), db2=g("sm_b"),
-                lr=st.lr if self.fused else (self.peer_exchange[1] if self.peer_exchange is not None else None),
-                peer=self.peer_exchange[0][q] if self.peer_exchange is not None else None)
+                lr=(st.lr if self.fused else self.async_push[1] if self.async_push is not None
+                    else self.peer_exchange[1] if self.peer_exchange is not None else None),
+                peer=self.peer_exchange[0][q] if self.peer_exchange is not None else None,
+                async_push=self.async_push[0] if self.async_push is not None else None)
         return out
 
     def use_gradient_slots(self, slots) -> None:
@@ -173,6 +176,17 @@ class MLPProgram:
         self.use_gradient_slots(slots)
         self.peer_exchange = (list(peers), float(lr_over_r))
         self._args = [self._build_args(q) for q in range(self.P)]
+
+    def use_async_push(self, async_struct, lr: float) -> None:
+        """Async mode on the two-launch step: the backward launch applies ``lr * gradient`` to the mapped master
+        slices (``async_struct``: ``Mlp2Async``) and keeps the result as the local replica; no gradients are stored."""
+        if not self.fused2 or self.fused or self.gs_inc != 0:
+            raise ValueError("the in-launch async push needs the two-launch step with global_step left to the ps")
+        self.async_push = (async_struct, float(lr))
+        self.peer_exchange = self.grad_slots = None
+        self._args = [self._build_args(q) for q in range(self.P)]
+        self._schedules.clear()
+        self._graphs.clear()
 
     def _launch_cached(self, key, build):
         """Argument structs of a launch are built once per (step parity, call site) and reused: the

@@ -145,7 +145,21 @@ class PeerMappedAsyncEngine:
             raise PeerMappedUnavailable("the peer-mapped push/pull failed its start-up check on this machine")
         self.publish_state()
         entry = (OP_ASYNC_PUSH_PULL, self._push, 0)
-        if hasattr(program, "schedule_tail_entries"):
+        # Opt-in (DTF_PEER_ASYNC_FUSED=1): the backward launch of the two-launch step pushes and pulls tile by tile,
+        # two launches per step.  Measured on one rank: the launch then ends 2.9 us later (it has to see its stores
+        # to the uncached master acknowledged), the separate push/pull kernel costs 3.9 us under the profiler and
+        # 3.0 us in the step: 14.8 us/step either way, so the simpler sequence stays the default.
+        self.fused = bool(getattr(program, "fused2", False)) and os.environ.get("DTF_PEER_ASYNC_FUSED", "0") == "1"
+        if self.fused:
+            a = _lib.Mlp2Async()
+            for s in range(self.S):
+                a.master[s] = self._base[s]
+                a.counters[s] = self._base[s] + self.slice * 4
+            a.params_base, a.slice, a.shards, a.pad_ = state.params.data_ptr(), self.slice, self.S, 0
+            self._mlp2_async = a
+            program.use_async_push(a, state.lr)
+            program.after_compute = None
+        elif hasattr(program, "schedule_tail_entries"):
             program.schedule_tail_entries.append(entry)
             program._schedules.clear()
             program.after_compute = None

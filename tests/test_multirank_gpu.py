@@ -121,8 +121,9 @@ def test_ranks_sync_with_peer_mapped_allreduce(world, fused):
     np.testing.assert_allclose(a["params"], c["params"], rtol=1e-4, atol=1e-6)
 
 
-def _peer_async_gpu(rank, world, port, shards):
+def _peer_async_gpu(rank, world, port, shards, fused="0"):
     os.environ["DTF_PEER_ASYNC"] = "1"
+    os.environ["DTF_PEER_ASYNC_FUSED"] = fused
     from distributed_tensorflow_amd.data import mnist
     from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
     from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
@@ -153,11 +154,12 @@ def _peer_async_gpu(rank, world, port, shards):
     return out
 
 
-@pytest.mark.parametrize("world,shards", [(3, 1), (4, 2)])
-def test_peer_mapped_async_engine_on_one_gpu(world, shards):
+@pytest.mark.parametrize("world,shards,fused", [(3, 1, "0"), (4, 2, "0"), (3, 2, "1")])
+def test_peer_mapped_async_engine_on_one_gpu(world, shards, fused):
     """Device-side Hogwild: every worker applies its gradients to the owners' mapped slices with one kernel per
-    step; global_step counts all updates; after the last push everybody pulls the same parameters."""
-    res = run_ranks(_peer_async_gpu, world, shards)
+    step (or, fused, inside the backward launch); global_step counts all updates; after the last push everybody
+    pulls the same parameters."""
+    res = run_ranks(_peer_async_gpu, world, shards, fused)
     assert all(r["kind"] == "PeerMappedAsyncEngine" for r in res)
     assert all(r["gs"] == 1 + world * 30 for r in res)
     for r in range(shards):
