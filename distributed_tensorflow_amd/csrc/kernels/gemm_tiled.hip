@@ -8,7 +8,11 @@
 //   backward   dX = dY . W^T      A = dY [batch,out]    B = W   [in,out]      (* (act > 0))
 //   gradient   dW = X^T . dY      A = X^T [in,batch]    B = dY^T [out,batch]  (+ db = rowsum(dY^T))
 //
-// Tile: 128x128 per workgroup, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles of 16x16.
+// This file: the register-staged 4-wave kernels, which take every shape (ragged edges through the range check of
+// the buffer loads) and both dtypes; large aligned bf16 products go to the 8-wave kernel in gemm_pingpong.hip
+// (dispatch in launch_tiled below).
+// Tile: 128x128 per workgroup, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles of 16x16 (or 256x256 with 8x8
+// tiles per wave, see the template parameters).
 // K-step per LDS stage: 128 bytes per row (64 bf16 / 32 fp32), two stages (double buffer),
 // register-staged: the global loads of stage t+1 are issued before the MFMAs of stage t and
 // written to the other LDS buffer after them, one barrier per stage.
