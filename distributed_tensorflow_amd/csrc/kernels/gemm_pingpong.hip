@@ -1,5 +1,5 @@
 // bf16 GEMM  C[M,N] = A[M,K] . B[N,K]^T  for the large aligned products of the wide layers
-// (M, N multiples of 256, K a multiple of 8): 256x256 block, 8 waves in two groups that alternate on the
+// (M, N, K multiples of 8; it pays from ~192 blocks of 256x256 on): 256x256 block, 8 waves in two groups that alternate on the
 // SIMDs ("ping-pong"): while one group issues its MFMAs, the other issues fragment reads and staging loads.
 //
 // Layout of the work
@@ -61,7 +61,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, g = lane >> 4;
 
-  const int tiles_n = p.N >> 8, tiles_m = p.M >> 8;
+  // M and N need not be multiples of 256: operand rows past the end are read out of range (zeros) or belong to a
+  // larger buffer (finite or not, they only feed output rows/columns that are never stored), the epilogue guards
+  const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 255) >> 8;
   const int wg = dtf_xcd_remap(blockIdx.x, tiles_m * tiles_n);
   // consecutive (remapped) ids walk down a band of 8 row-tiles: the A panels and one B panel stay in that XCD's L2
   const int band = 8;
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
       for (int it = 0; it < 16; ++it) {
         const int R = it * 4 + (lane >> 4), q = lane & 15;
         const float4 v = *reinterpret_cast<const float4*>(&wl[R * 256 + (((q ^ (R >> 2)) & 15) << 4)]);
-        *reinterpret_cast<float4*>(&Cf[(size_t)(crow + ha * 64 + R) * p.ldc + ccol + q * 4]) = v;
+        if (crow + ha * 64 + R < p.M && ccol + q * 4 < p.N)      // N is a multiple of 8: a chunk is inside or outside
+          *reinterpret_cast<float4*>(&Cf[(size_t)(crow + ha * 64 + R) * p.ldc + ccol + q * 4]) = v;
       }
     }
   } else {
@@ -237,7 +240,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int col = ccol + hb * 32 + 16 * j + fr;
-        const float bias = (EPI == EPI_FWD && p.bias) ? p.bias[col] : 0.f;
+        const bool col_ok = col < p.N;
+        const float bias = (EPI == EPI_FWD && p.bias && col_ok) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -251,14 +255,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
               for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             if (EPI == EPI_BWD) {
-              // the lane's four rows are contiguous in the transposed mask
-              const uint2 q = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.maskT) + (size_t)col * p.ldmaskt + row0);
+              // the lane's four rows are contiguous in the transposed mask (M is a multiple of 8: all four or none)
+              const bool in = col_ok && row0 < p.M;
+              const uint2 q = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.maskT) + (in ? (size_t)col * p.ldmaskt + row0 : 0));
               const float mk[4] = {pp_bf2f((unsigned short)(q.x & 0xffff)), pp_bf2f((unsigned short)(q.x >> 16)),
                                    pp_bf2f((unsigned short)(q.y & 0xffff)), pp_bf2f((unsigned short)(q.y >> 16))};
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
             }
-            if (p.C32) {
+            if (p.C32 && col_ok && row0 < p.M) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) p.C32[(size_t)(row0 + r) * p.ldc32 + col] = v[r];
             }
@@ -283,7 +288,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
       for (int it = 0; it < 16; ++it) {
         const int c = it * 4 + (lane >> 4), q = lane & 15;
         const u32x4 v = *reinterpret_cast<const u32x4*>(&wl[c * 256 + ((q ^ (c & 15)) << 4)]);
-        *reinterpret_cast<u32x4*>(&Ct[(size_t)(ccol + c) * p.ldct + crow + q * 8]) = v;
+        if (ccol + c < p.N && crow + q * 8 < p.M)
+          *reinterpret_cast<u32x4*>(&Ct[(size_t)(ccol + c) * p.ldct + crow + q * 8]) = v;
       }
     }
     // row-major image [128 rows][64 columns] bf16: row R, 16-byte chunk (columns 8q..8q+7) at q ^ ((R >> 2) & 7)
@@ -309,7 +315,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
     for (int it = 0; it < 16; ++it) {
       const int R = it * 8 + (lane >> 3), q = lane & 7;
       const u32x4 v = *reinterpret_cast<const u32x4*>(&wl[R * 128 + (((q ^ (R >> 2)) & 7) << 4)]);
-      *reinterpret_cast<u32x4*>(&C[(size_t)(crow + R) * p.ldc + ccol + q * 8]) = v;
+      if (crow + R < p.M && ccol + q * 8 < p.N)
+        *reinterpret_cast<u32x4*>(&C[(size_t)(crow + R) * p.ldc + ccol + q * 8]) = v;
     }
   }
   if (want_bias) {
@@ -321,15 +328,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
         float s = bias_grad[hb][j];
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (g == 0) p.bias_out[n0 + wc * 64 + hb * 32 + 16 * j + fr] = s;
+        if (g == 0 && n0 + wc * 64 + hb * 32 + 16 * j + fr < p.N) p.bias_out[n0 + wc * 64 + hb * 32 + 16 * j + fr] = s;
       }
   }
 }
 
-// Shapes this kernel takes: bf16, M and N multiples of 256, K a multiple of 8 (16-byte chunks) and at least 256,
-// the transposed mask for the backward epilogue, outputs that take 16-byte stores.
+// Shapes this kernel takes: bf16, M, N and K multiples of 8 (16-byte chunks of operands and outputs), K at least
+// 256, the transposed mask for the backward epilogue, outputs that take 16-byte stores.  Whether it PAYS (enough
+// 256x256 blocks to fill the chip, little waste at ragged edges) is the caller's decision.
 bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a) {
-  if (a.dtype != 1 || (a.M & 255) || (a.N & 255) || (a.K & 7) || a.K < 256) return false;
+  if (a.dtype != 1 || (a.M & 7) || (a.N & 7) || (a.K & 7) || a.K < 256) return false;
   if (a.epilogue == EPI_BWD && (!a.maskT || (a.ldmaskt & 3))) return false;
   if ((reinterpret_cast<uintptr_t>(a.C) & 15) || (a.ldc & (a.epilogue == EPI_WGRAD ? 3 : 7))) return false;
   if (a.Ct && ((a.ldct & 7) || (reinterpret_cast<uintptr_t>(a.Ct) & 15))) return false;
@@ -339,7 +347,7 @@ bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a) {
 
 int dtf_gemm_pingpong_launch(const DtfGemmArgs& a, hipStream_t s) {
   if (!dtf_gemm_pingpong_takes(a)) return DTF_ERR_SHAPE;
-  dim3 grid((a.M >> 8) * (a.N >> 8)), block(512);
+  dim3 grid(((a.M + 255) >> 8) * ((a.N + 255) >> 8)), block(512);
   switch (a.epilogue) {
     case EPI_FWD: hipLaunchKernelGGL(gemm_pp_kernel<EPI_FWD>, grid, block, 0, s, a); break;
     case EPI_BWD: hipLaunchKernelGGL(gemm_pp_kernel<EPI_BWD>, grid, block, 0, s, a); break;

@@ -338,7 +338,7 @@ static int launch_tiled(const DtfGemmArgs& a, hipStream_t s) {
     const char* e = getenv("DTF_GEMM_PINGPONG");
     g_pingpong_mode = e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)) : 2;
   }
-  if (sizeof(T) == 2 && g_pingpong_mode && dtf_gemm_pingpong_takes(a) && (g_pingpong_mode == 1 || big_tiles >= 192))
+  if (sizeof(T) == 2 && g_pingpong_mode && dtf_gemm_pingpong_takes(a) && (g_pingpong_mode == 1 || fits))
     return dtf_gemm_pingpong_launch(a, s);
   if (sizeof(T) == 2 && (g_big_tile_mode == 1 || (g_big_tile_mode == 2 && fits && suited))) return launch_tiled_as<T, 8, 8>(a, s);
   return launch_tiled_as<T, 4, 4>(a, s);

@@ -114,7 +114,8 @@ def pingpong_kernel():
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 768, 384), (768, 256, 1024), (256, 1024, 128 * 7),
-                                   (512, 256, 784), (256, 512, 264), (256, 256, 448)])
+                                   (512, 256, 784), (256, 512, 264), (256, 256, 448),
+                                   (264, 520, 256), (1000, 776, 328), (8, 8, 256), (504, 248, 512)])
 def test_pingpong_kernel_all_epilogues(pingpong_kernel, M, N, K):
     """The 8-wave direct-to-LDS kernel against fp32 statements; operands asymmetric so that a swapped tile, half
     or k-chunk anywhere in the staging/fragment maps shows."""
