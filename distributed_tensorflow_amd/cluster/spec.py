@@ -110,12 +110,17 @@ class Role:
         return same.index(self.task_index)
 
 
-def validate_role(job_name, task_index) -> None:
-    """The two checks of distributed.py:40-47, same messages."""
+def validate_role(job_name, task_index, echo=None) -> None:
+    """The two checks of distributed.py:40-47, same messages, in the same order: with ``echo`` (a print function)
+    the accepted job name is printed before the task index is examined, as in the reference."""
     if job_name is None or job_name == '':
         raise ValueError('Must specify an explicit job_name !')
+    if echo is not None:
+        echo('job_name : %s' % job_name)
     if task_index is None or task_index == '':
         raise ValueError('Must specify an explicit task_index!')
+    if echo is not None:
+        echo('task_index : %d' % task_index)
 
 
 def round_robin_placement(variable_names: Sequence[str], num_ps: int) -> Dict[str, int]:

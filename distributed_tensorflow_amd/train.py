@@ -212,9 +212,7 @@ def main(unused_argv=None) -> int:
             FLAGS.job_name = "worker"
         if FLAGS.task_index is None:
             FLAGS.task_index = 0
-    validate_role(FLAGS.job_name, FLAGS.task_index)                                        # :40-47
-    print('job_name : %s' % FLAGS.job_name)
-    print('task_index : %d' % FLAGS.task_index)
+    validate_role(FLAGS.job_name, FLAGS.task_index, echo=print)                            # :40-47
 
     if FLAGS.single_process:
         ps_spec, worker_spec = [], ["127.0.0.1:0"]

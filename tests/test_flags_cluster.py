@@ -53,6 +53,14 @@ def test_missing_role_raises_value_error_with_reference_messages():
     with pytest.raises(ValueError, match='Must specify an explicit task_index!'):
         validate_role('worker', None)
     validate_role('ps', 0)
+    # the job name is echoed before the task index is examined (distributed.py:40-47)
+    said = []
+    with pytest.raises(ValueError):
+        validate_role('worker', None, echo=said.append)
+    assert said == ['job_name : worker']
+    said.clear()
+    validate_role('worker', 3, echo=said.append)
+    assert said == ['job_name : worker', 'task_index : 3']
 
 
 def test_cluster_spec_and_roles():
