@@ -93,7 +93,7 @@ def test_r_greater_than_n_accumulates_several_rounds():
     params = oracle.init_params(16, seed=3)
     data = [_batches(r, 2 * steps) for r in range(world)]
     for s in range(steps):
-        contrib = [data[0][2 * s], data[1][2 * s], data[0][2 * s + 1]]             # rank 1 is slow in round 2
+        contrib = [data[0][2 * s], data[1][2 * s], data[0][2 * s + 1]]             # rank 1 is slow in the second pass
         grads = [oracle.loss_and_grads(params, *c)[2] for c in contrib]
         mean = {k: sum(g[k] for g in grads) / R for k in params}
         params = oracle.sgd(params, mean, LR)
