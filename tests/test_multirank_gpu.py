@@ -192,6 +192,36 @@ def test_cli_async_workers_use_the_device_side_engine(monkeypatch):
     assert s0[-1][2] < s0[0][2] - 0.2 and s1[-1][2] < s1[0][2] - 0.2
 
 
+def _bench_two_ranks(config, extra, steps, warmup, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DTF_DIST_BACKEND="gloo", DTF_SHARE_GPU="1", **(env_extra or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup",
+           str(warmup), "--config", config] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=200, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 prints ONE JSON line, nothing else on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config,extra,collective", [
+    ("wide_mlp_sync", ["--dtype", "bf16", "--hidden_units", "1024", "--batch_size", "256"], "bucketed"),
+    ("wide_mlp_async", ["--dtype", "bf16", "--hidden_units", "512", "--batch_size", "256"], None),
+    ("resnet50_sync", ["--batch_size", "8"], "bucketed")])
+def test_bench_launch_line_of_the_large_configs_with_two_ranks(config, extra, collective):
+    """The N > 1 code paths of the large configurations end to end (bucketed aggregation behind the backward pass,
+    owner-resident Adam for the async wide model), small sizes, two ranks sharing the GPU over gloo."""
+    d = _bench_two_ranks(config, extra, 4, 2, {"DTF_MIOPEN_FIND": "0"})
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
+    assert d.get("final_loss", 0.0) == d.get("final_loss", 0.0)          # not NaN where reported
+    if collective is not None:
+        assert d["config"]["collective"] == collective
+
+
 @pytest.mark.parametrize("config,expect", [("mlp_sync", ("peer_mapped_allreduce", True)),
                                            ("mlp_async", ("engine", "PeerMappedAsyncEngine"))])
 def test_bench_launch_line_with_two_ranks_sharing_the_gpu(config, expect):
