@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import os
+import sys
 import time
 
 import torch
@@ -63,9 +64,6 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     lr = 0.01 if optimizer == "sgd" else 1e-3
     train_rows = 55000 if not wide else max(8 * batch, 16384)
     ds = mnist.synthetic_data_sets(train_size=train_rows, validation_size=100, test_size=100, seed=rank)
-    state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer=optimizer, lr=lr)
-    state.initialize(seed=1234)                      # same seed everywhere == chief init + broadcast
-    data = DeviceDataset(ds.train, device, shuffle_seed=1000 + rank)
     force = bool(getattr(args, "force_collectives", False)) and world == 1 and device.type == "cuda"
     if force and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -73,18 +71,46 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     fused = world == 1 and optimizer == "sgd" and not wide and not force
     dtype_name = args.dtype or "fp32"
-    if wide:
-        cdtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
-        prog = WideMLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, dtype=cdtype, gs_inc=1)
-        args.no_post_update_accuracy = True
-    else:
-        prog = MLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, fused_update=fused,
-                          post_update_accuracy=not args.no_post_update_accuracy, gs_inc=1)
-    engine = SyncReplicasEngine(prog, state, collective=args.collective, force_collectives=force,
-                                capture_collectives=False if force else None)
     graph_steps = args.graph_steps or 64
+
+    def build():
+        state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer=optimizer, lr=lr)
+        state.initialize(seed=1234)                      # same seed everywhere == chief init + broadcast
+        data = DeviceDataset(ds.train, device, shuffle_seed=1000 + rank)
+        if wide:
+            cdtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+            prog = WideMLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, dtype=cdtype, gs_inc=1)
+            args.no_post_update_accuracy = True
+        else:
+            prog = MLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, fused_update=fused,
+                              post_update_accuracy=not args.no_post_update_accuracy, gs_inc=1)
+        engine = SyncReplicasEngine(prog, state, collective=args.collective, force_collectives=force,
+                                    capture_collectives=False if force else None)
+        return state, prog, engine
+
+    state, prog, engine = build()
     _sync_all(device, world)
-    engine.run(args.warmup, graph_steps) if args.warmup > 0 else None
+    # The warm-up doubles as the acceptance run of the peer-mapped transport on this machine: if any rank's wait
+    # for a peer runs into its limit, EVERY rank rebuilds the job on RCCL and warms up again (one decision for all)
+    failed = 0
+    try:
+        engine.run(args.warmup, graph_steps) if args.warmup > 0 else None
+    except RuntimeError as e:
+        if engine.p2p is None or world == 1:
+            raise
+        failed = 1
+        sys.stderr.write(f"[bench] rank {rank}: {e}\n")
+    if world > 1 and engine.p2p is not None:
+        t = torch.tensor([failed], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if int(t.item()):
+            sys.stderr.write(f"[bench] rank {rank}: peer-mapped transport gave up during warm-up; continuing on RCCL\n")
+            os.environ["DTF_P2P_ALLREDUCE"] = "0"
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            state, prog, engine = build()
+            _sync_all(device, world)
+            engine.run(args.warmup, graph_steps) if args.warmup > 0 else None
     _sync_all(device, world)
     t0 = time.perf_counter()
     engine.run(args.steps, graph_steps)

@@ -214,7 +214,7 @@ class SyncReplicasEngine:
         prog._schedules.clear()
         prog.after_compute = None
 
-    def _check_replicas(self) -> None:
+    def _check_replicas(self, late: bool = False) -> None:
         """After the first runs over peer-mapped buffers: every rank must hold bit-identical parameters (the kernels
         add the ranks' gradients in one order everywhere).  A difference means the machine orders the peer traffic
         differently from what the in-launch exchange assumes: the ranks then take rank 0's parameters and continue
@@ -223,9 +223,12 @@ class SyncReplicasEngine:
             return
         self._replica_checks_left -= 1
         p = self.state.params
-        digest = (float(p.double().sum().item()), float(p.double().square().sum().item()))
+        digest = (bool(late), float(p.double().sum().item()), float(p.double().square().sum().item()))
         seen = [None] * self.world
         dist.all_gather_object(seen, digest, group=self.coll.group)
+        if any(d[0] for d in seen):                  # raised on every rank together
+            raise RuntimeError("peer-mapped all-reduce: a peer's gradients did not arrive within the time limit "
+                               f"(ranks {[r for r, d in enumerate(seen) if d[0]]})")
         if all(d == seen[0] for d in seen):
             return
         import warnings
@@ -270,9 +273,18 @@ class SyncReplicasEngine:
             else:
                 self.program.run(n_steps, graph_steps)
             self.updates_applied += n_steps
-            if self.p2p is not None and self.p2p.timed_out():
-                raise RuntimeError("peer-mapped all-reduce: a peer's gradients did not arrive within the time limit")
-            self._check_replicas()
+            if self.p2p is not None:
+                late = self.p2p.timed_out()
+                if self._replica_checks_left > 0:
+                    self._check_replicas(late)      # collective: every rank learns of any rank's time-out
+                else:
+                    if self.world > 1:              # one decision for all ranks (a 4-byte all-reduce per run() call)
+                        t = torch.tensor([1 if late else 0], dtype=torch.int32,
+                                         device=self.state.device if self.coll.backend == "nccl" else "cpu")
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.coll.group)
+                        late = bool(t.item())
+                    if late:
+                        raise RuntimeError("peer-mapped all-reduce: a peer's gradients did not arrive within the time limit")
             return
         for _ in range(n_steps):
             self._general_update()

@@ -222,6 +222,13 @@ def test_bench_launch_line_of_the_large_configs_with_two_ranks(config, extra, co
         assert d["config"]["collective"] == collective
 
 
+def test_bench_falls_back_to_the_process_group_when_the_peer_transport_gives_up():
+    """A peer wait that runs into its limit during the warm-up (here: a limit of 100 ns) makes every rank rebuild
+    the job without the peer-mapped transport; the JSON line says so."""
+    d = _bench_two_ranks("mlp_sync", [], 60, 20, {"DTF_P2P_ALLREDUCE": "1", "DTF_P2P_TIMEOUT_S": "1e-7"})
+    assert d["config"]["peer_mapped_allreduce"] is False and d["n_gpus"] == 2 and d["value"] > 0
+
+
 @pytest.mark.parametrize("config,expect", [("mlp_sync", ("peer_mapped_allreduce", True)),
                                            ("mlp_async", ("engine", "PeerMappedAsyncEngine"))])
 def test_bench_launch_line_with_two_ranks_sharing_the_gpu(config, expect):
