@@ -25,6 +25,9 @@ void* dtf_bundle_reader_open(const char*, char*, size_t);
 int dtf_bundle_reader_num_entries(void*);
 int dtf_bundle_reader_read(void*, const char*, void*, size_t);
 void dtf_bundle_reader_close(void*);
+void* dtf_events_open(const char*, double);
+int dtf_events_scalar(void*, double, int64_t, const char*, float);
+int dtf_events_close(void*);
 void* dtf_idx_open(const char*, char*, size_t);
 int dtf_idx_ndim(void*);
 int64_t dtf_idx_dim(void*, int);
@@ -56,6 +59,22 @@ static void test_crc() {
   CHECK(dtf_crc32c("123456789", 9) == 0xE3069283u);          // the CRC-32C check value
   const uint32_t c = dtf_crc32c("123456789", 9);
   CHECK(dtf_crc32c_masked("123456789", 9) == (((c >> 15) | (c << 17)) + 0xa282ead8u));
+}
+
+static void test_events(const std::string& dir) {
+  const std::string path = dir + "/events.out.tfevents.selftest";
+  remove(path.c_str());
+  void* w = dtf_events_open(path.c_str(), 1.5);
+  CHECK(w != nullptr);
+  CHECK(dtf_events_scalar(w, 2.5, 7, "global_step/sec", 3.25f) == 0);
+  CHECK(dtf_events_scalar(w, 2.5, -1, "x", 0.f) != 0);          // negative step refused
+  CHECK(dtf_events_close(w) == 0);
+  FILE* f = fopen(path.c_str(), "rb");
+  CHECK(f != nullptr);
+  fseek(f, 0, SEEK_END);
+  // version record: 12 + 24 + 4; scalar record: 12 + (9 + 2 + 2 + (2 + (2 + 15 + 5))) + 4
+  CHECK(ftell(f) == 40 + 12 + 37 + 4);
+  fclose(f);
 }
 
 static void test_bundle(const std::string& dir) {
@@ -217,6 +236,7 @@ int main(int argc, char** argv) {
   const std::string dir = argc > 1 ? argv[1] : "/tmp";
   test_crc();
   test_bundle(dir);
+  test_events(dir);
   test_idx(dir);
   test_ps_service();
   if (failures) {

@@ -29,7 +29,8 @@ from ..checkpoint.saver import Saver, latest_checkpoint
 class Supervisor:
     def __init__(self, is_chief: bool, logdir: Optional[str], init_fn: Callable[[], None], state,
                  recovery_wait_secs: float = 1.0, save_model_secs: float = 600.0, save_summaries_secs: float = 120.0,
-                 store=None, group_size: int = 1, saver: Optional[Saver] = None, log: Callable[[str], None] = print):
+                 store=None, group_size: int = 1, saver: Optional[Saver] = None, log: Callable[[str], None] = print,
+                 examples_per_global_step: Optional[int] = None):
         self.is_chief = is_chief
         self.logdir = logdir if logdir is not None else tempfile.mkdtemp()   # distributed.py:109
         self.init_fn = init_fn
@@ -37,6 +38,8 @@ class Supervisor:
         self.recovery_wait_secs = recovery_wait_secs
         self.save_model_secs = save_model_secs
         self.save_summaries_secs = save_summaries_secs
+        # batch x R in sync mode, batch in async mode: turns global_step/sec into the examples/sec of the whole job
+        self.examples_per_global_step = examples_per_global_step
         self.store = store
         self.group_size = group_size
         self.saver = saver or Saver()
@@ -47,6 +50,7 @@ class Supervisor:
         self._last_rate_step: Optional[int] = None
         self.waited_polls = 0
         self._events = None
+        self._tb = None                  # TensorBoard event file (events.out.tfevents.*), chief only
 
     # ------------------------------------------------------------------ session bring-up
     def prepare_or_wait_for_session(self) -> None:
@@ -111,8 +115,20 @@ class Supervisor:
             if self._events is None:
                 os.makedirs(self.logdir, exist_ok=True)
                 self._events = open(os.path.join(self.logdir, "events.jsonl"), "a")
-            self._events.write(json.dumps({"wall_time": now, "step": global_step, "global_step/sec": rate}) + "\n")
+                try:        # the TensorBoard file needs the native runtime; the JSON lines are always written
+                    from ..utils.tfevents import EventFileWriter
+                    self._tb = EventFileWriter(self.logdir, now)
+                except (OSError, ImportError, AttributeError):
+                    self._tb = None
+            rec = {"wall_time": now, "step": global_step, "global_step/sec": rate}
+            if self.examples_per_global_step:
+                rec["examples/sec"] = rate * self.examples_per_global_step
+            self._events.write(json.dumps(rec) + "\n")
             self._events.flush()
+            if self._tb is not None:
+                self._tb.add_scalar("global_step/sec", rate, global_step, now)
+                if self.examples_per_global_step:
+                    self._tb.add_scalar("examples/sec", rec["examples/sec"], global_step, now)
         return rate
 
     def stop(self, save: bool = True) -> None:
@@ -121,3 +137,6 @@ class Supervisor:
         if self._events is not None:
             self._events.close()
             self._events = None
+        if self._tb is not None:
+            self._tb.close()
+            self._tb = None

@@ -246,7 +246,9 @@ def main(unused_argv=None) -> int:
     seed = FLAGS.seed if FLAGS.seed else (int(time.time() * 1000) & 0x7FFFFFFF)
     sv = Supervisor(is_chief=is_chief, logdir=FLAGS.train_dir, init_fn=lambda: state.initialize(seed), state=state,
                     recovery_wait_secs=1, save_model_secs=FLAGS.save_model_secs, store=server.store,
-                    group_size=num_workers)                                                # :108-111
+                    group_size=num_workers,                                                # :108-111
+                    examples_per_global_step=FLAGS.batch_size * ((FLAGS.replicas_to_aggregate or num_workers)
+                                                                 if FLAGS.sync_replicas else 1))
     if is_chief:
         print('Worker %d: Initailizing session...' % FLAGS.task_index)                     # :122
     else:

@@ -4,6 +4,7 @@ import os
 import threading
 import time
 
+import pytest
 import torch
 import torch.distributed as dist
 
@@ -82,3 +83,31 @@ def test_periodic_checkpoint_and_step_rate(tmp_path):
     assert ev[0]["step"] == 50 and "global_step/sec" in ev[0]
     non_chief = Supervisor(False, str(tmp_path), lambda: None, st)
     assert non_chief.save() is None                                # only the chief writes checkpoints
+
+
+def test_event_file_is_tensorboard_framed(tmp_path):
+    """The chief's global_step/sec summaries go to an events.out.tfevents.* file (TFRecord framing with masked
+    crc32c, Event/Summary protobufs) written by the native runtime and parsed back by an independent reader."""
+    import glob
+    from distributed_tensorflow_amd.utils import native
+    from distributed_tensorflow_amd.utils.tfevents import EventFileWriter, read_events
+    if not native.available():
+        pytest.skip("native runtime not built")
+    w = EventFileWriter(str(tmp_path), now=1700000000.25)
+    w.add_scalar("global_step/sec", 1234.5, 100, 1700000001.0)
+    w.add_scalar("examples/sec", 8.5e6, 300, 1700000002.0)
+    w.close()
+    (path,) = glob.glob(str(tmp_path / "events.out.tfevents.1700000000.*"))
+    ev = read_events(path)
+    assert ev[0]["file_version"] == "brain.Event:2" and ev[0]["wall_time"] == 1700000000.25
+    assert ev[1]["step"] == 100 and abs(ev[1]["scalars"]["global_step/sec"] - 1234.5) < 1e-3
+    assert ev[2]["step"] == 300 and ev[2]["scalars"]["examples/sec"] == pytest.approx(8.5e6)
+    # first record byte for byte: length 24, Event{wall_time, file_version}
+    raw = open(path, "rb").read()
+    assert raw[:8] == (24).to_bytes(8, "little") and raw[12:13] == b"\x09" and raw[21:23] == b"\x1a\x0d"
+    # a flipped byte is detected
+    bad = bytearray(raw)
+    bad[40] ^= 1
+    open(path, "wb").write(bytes(bad))
+    with pytest.raises(ValueError):
+        read_events(path)
