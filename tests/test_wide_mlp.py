@@ -60,3 +60,22 @@ def test_gpu_wide_shapes_4096():
     recs = prog.read_log(0, 6)
     assert recs[-1].loss < recs[0].loss
     assert all(torch.isfinite(torch.tensor(r.loss)) for r in recs)
+
+
+@pytest.mark.gpu
+def test_gpu_wide_pipeline_is_identical_on_both_gemm_kernels():
+    """The 8-wave ping-pong GEMM inside the training pipeline (forward with transposed/fp32 copies, masked backward
+    reading the transposed activations, weight + bias gradients, ragged K = 784 of the first layer): the trajectory
+    must equal the one of the 4-wave register-staged kernels bit for bit (same MFMA, same accumulation order)."""
+    out = {}
+    for mode in (1, 0):
+        ops.gemm_set_modes(pingpong=mode)
+        try:
+            _, st, prog = _run(WideMLPProgram, "cuda", 8, "adam", 1e-3, hidden=[512, 256, 512], batch=256, dtype=torch.bfloat16)
+            torch.cuda.synchronize()
+            out[mode] = (st.params.clone(), [r.loss for r in prog.read_log(0, 8)])
+        finally:
+            ops.gemm_set_modes(pingpong=2)
+    assert out[1][1] == out[0][1]
+    assert torch.equal(out[1][0], out[0][0])
+    assert out[1][1][-1] < out[1][1][0]
