@@ -209,6 +209,9 @@ DTF_EXPORT int dtf_small_gemm(const DtfSmallGemmArgs* a, hipStream_t s) {
 #define DTF_WGRAD_CH 7
 #endif
 
+// CH: 16*CH batch rows per pass (row indices, then every operand load, then the MFMAs); 7 covers the reference
+// batch of 100 in one pass, 16 quarters the number of dependent passes of a 4096-row batch.
+template <int CH>
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
   const int nblk_tiles = (p.total_tiles + 3) >> 2;
   if ((int)blockIdx.x >= nblk_tiles) {
@@ -252,7 +255,6 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
   }
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  constexpr int CH = DTF_WGRAD_CH;   // 16*CH batch rows per pass: row indices, then every operand load, then the MFMAs
   for (int kb = 0; kb < q.Kb; kb += 16 * CH) {
     int xr[CH][4];
     float av[CH][4], bv[CH][4];
@@ -323,7 +325,10 @@ DTF_EXPORT int dtf_wgrad_grouped(const DtfWgradArgs* a, hipStream_t s) {
     if (a->tail.nparts > 0 && (!a->tail.loss_part || !a->tail.correct_part || !a->tail.post_part)) return DTF_ERR_ARG;
   }
   const int nblk = dtf_cdiv(tiles, 4) + 1;
-  hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(nblk), dim3(256), 0, s, *a);
+  bool long_k = true;
+  for (int i = 0; i < a->nprob; ++i) long_k = long_k && a->prob[i].Kb >= 1024;
+  if (long_k) hipLaunchKernelGGL(wgrad_grouped_kernel<16>, dim3(nblk), dim3(256), 0, s, *a);
+  else hipLaunchKernelGGL(wgrad_grouped_kernel<DTF_WGRAD_CH>, dim3(nblk), dim3(256), 0, s, *a);
   return dtf_check_launch();
 }
 
@@ -339,6 +344,9 @@ DTF_EXPORT int dtf_wgrad_grouped(const DtfWgradArgs* a, hipStream_t s) {
 #define DTF_HEAD_CH 2
 #endif
 
+// CH = 16-wide k-chunks (phase A) / column chunks (phase C) whose loads a wave has in flight per pass: 2 keeps the
+// serial chain of the 100-unit reference layer short, 8 gives a 4096-unit layer 4x fewer dependent passes.
+template <int CH>
 __global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
   __shared__ float red[4][4][64];
   __shared__ float dzs[16][17];
@@ -353,7 +361,6 @@ __global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
   const bool cls_ok = fr < C;
   const bool train_tile = r0 < p.M_train && p.dz1 != nullptr;   // workgroup-uniform
   const int nchunk = (Hd + 15) >> 4;
-  constexpr int CH = DTF_HEAD_CH;
   const rsrc_t rh = make_rsrc(p.Hact, p.h_bytes), rw = make_rsrc(p.W2, (unsigned)Hd * (unsigned)C * 4u);
 
   // ---- phase A: z2 = Hact @ W2 (16 rows x 16 padded classes), split-K over the waves ----
@@ -502,6 +509,7 @@ DTF_EXPORT int dtf_head(const DtfHeadArgs* a, hipStream_t s) {
   if (((a->ldh | a->Hd) & 3) == 0 && !dtf_aligned16(a->Hact)) return DTF_ERR_ALIGN;
   if (a->h_bytes == 0 || a->h_bytes >= kOOB || ((uint64_t)(a->M_total - 1) * a->ldh + a->Hd) * 4u > a->h_bytes) return DTF_ERR_SHAPE;
   if ((uint64_t)a->Hd * a->C * 4u >= kOOB) return DTF_ERR_SHAPE;
-  hipLaunchKernelGGL(head_kernel, dim3(dtf_cdiv(a->M_total, 16)), dim3(256), 0, s, *a);
+  if (a->Hd >= 1024) hipLaunchKernelGGL(head_kernel<8>, dim3(dtf_cdiv(a->M_total, 16)), dim3(256), 0, s, *a);
+  else hipLaunchKernelGGL(head_kernel<DTF_HEAD_CH>, dim3(dtf_cdiv(a->M_total, 16)), dim3(256), 0, s, *a);
   return dtf_check_launch();
 }
