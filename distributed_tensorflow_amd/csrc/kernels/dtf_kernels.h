@@ -180,6 +180,18 @@ struct DtfGemmArgs {
   const void* maskT;      // optional transposed mask [N, ldmaskt]: the 4 rows a lane owns are one 8/16-byte load
   int ldmaskt;
   int pad_;
+  // Weight-gradient epilogue with the optimizer folded in (one worker, no aggregation; 8-wave kernel only): the
+  // gradient tile never goes to memory, the epilogue reads master weights (and Adam moments) laid out like C,
+  // writes them back updated and emits the compute-dtype copies W [M,N] (ld = ldc) and W^T [N, ldwt].
+  float* opt_p;           // master weights [M, ldc]; null = plain weight gradient into C
+  float* opt_m;           // Adam moments [M, ldc]; both null = SGD
+  float* opt_v;
+  void* opt_w;            // compute-dtype copy of the updated weights, optional
+  void* opt_wt;           // ... transposed [N, ldwt], optional
+  const int* opt_step;    // device counter of applied updates (Adam bias correction uses *opt_step + opt_step_offset)
+  int opt_step_offset;
+  int ldwt;
+  float opt_lr, opt_b1, opt_b2, opt_eps;
 };
 
 // A pre-validated launch sequence: the hand-scheduled step (what a graph partitioner + executor do
@@ -262,6 +274,8 @@ DTF_EXPORT int dtf_run_schedule(const DtfScheduleEntry* entries, int n, hipStrea
 
 DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s);
 DTF_EXPORT void dtf_gemm_set_modes(int big_tile, int pingpong);
+// dstT[N, ldt] = src[M, lds]^T for 2-byte elements; M, N, lds, ldt multiples of 8, 16-byte aligned bases.
+DTF_EXPORT int dtf_transpose16(const void* src, void* dstT, int M, int N, int lds_, int ldt, hipStream_t s);
 DTF_EXPORT int dtf_gather_cast_transpose(const float* src, const int* rows, void* dst, void* dstT, int M, int N, int lds_,
                                          int ldd, int ldt, int dtype, hipStream_t s);
 DTF_EXPORT int dtf_small_gemm(const DtfSmallGemmArgs* a, hipStream_t s);

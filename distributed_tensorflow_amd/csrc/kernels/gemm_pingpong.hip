@@ -46,7 +46,7 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 static constexpr unsigned kOOB = 0xFFFFFFF0u;
 
-enum { EPI_FWD = 0, EPI_BWD = 1, EPI_WGRAD = 2 };
+enum { EPI_FWD = 0, EPI_BWD = 1, EPI_WGRAD = 2, EPI_WGRAD_OPT = 3 };   // 3: weight gradient with the optimizer folded in
 enum { REG_A0 = 0, REG_A1 = 1, REG_B0 = 2, REG_B1 = 3 };
 
 __device__ __forceinline__ unsigned short pp_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bias_grad[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  const bool want_bias = EPI == EPI_WGRAD && p.bias_out != nullptr && tm == 0 && wr == 0;   // wave-uniform
+  const bool want_bias = (EPI == EPI_WGRAD || EPI == EPI_WGRAD_OPT) && p.bias_out != nullptr && tm == 0 && wr == 0;   // wave-uniform
 
   u32x4 af[4][2], bq0[2][2], bq1[2][2];
 
@@ -204,8 +204,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
   typedef unsigned short T;
   unsigned char* const wl = lds + wave * 16384;
   const int crow = m0 + wr * 128, ccol = n0 + wc * 64;          // origin of this wave's block
-  if (EPI == EPI_WGRAD) {
+  if (EPI == EPI_WGRAD || EPI == EPI_WGRAD_OPT) {
     float* __restrict__ Cf = static_cast<float*>(p.C);
+    // optimizer folded into the epilogue: the same arithmetic as optim.hip (adam_one / sgd), element for element
+    constexpr bool opt = EPI == EPI_WGRAD_OPT;
+    const bool adam = p.opt_m != nullptr;
+    float lr_t = p.opt_lr, eps_t = 0.f;
+    if (opt && adam) {
+      const int t = (p.opt_step ? *p.opt_step : 0) + p.opt_step_offset;
+      const float bc1 = 1.f - powf(p.opt_b1, (float)t), bc2 = 1.f - powf(p.opt_b2, (float)t);
+      const float sq = sqrtf(bc2);
+      lr_t = p.opt_lr * sq / bc1;
+      eps_t = p.opt_eps * sq;
+    }
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha) {
       // fp32 image of 64 rows x 64 columns: row R = 16i + 4g + r, 16-byte chunk (c >> 2) ^ ((R >> 2) & 15)
@@ -222,12 +233,62 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
               *reinterpret_cast<float*>(&wl[R * 256 + ((((c >> 2) ^ (R >> 2)) & 15) << 4) + (c & 3) * 4]) = acc[ha][i][hb][j][r];
             }
           }
+      if (!opt) {
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int R = it * 4 + (lane >> 4), q = lane & 15;
-        const float4 v = *reinterpret_cast<const float4*>(&wl[R * 256 + (((q ^ (R >> 2)) & 15) << 4)]);
-        if (crow + ha * 64 + R < p.M && ccol + q * 4 < p.N)      // N is a multiple of 8: a chunk is inside or outside
-          *reinterpret_cast<float4*>(&Cf[(size_t)(crow + ha * 64 + R) * p.ldc + ccol + q * 4]) = v;
+        for (int it = 0; it < 16; ++it) {
+          const int R = it * 4 + (lane >> 4), q = lane & 15;
+          const float4 v = *reinterpret_cast<const float4*>(&wl[R * 256 + (((q ^ (R >> 2)) & 15) << 4)]);
+          if (crow + ha * 64 + R < p.M && ccol + q * 4 < p.N)      // N is a multiple of 8: a chunk is inside or outside
+            *reinterpret_cast<float4*>(&Cf[(size_t)(crow + ha * 64 + R) * p.ldc + ccol + q * 4]) = v;
+        }
+      } else {
+        // two row groups at a time (6 parameter loads in flight per lane before the first use); the fence keeps
+        // the compiler from hoisting every group's loads to the top, which would not fit the register file
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib) {
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 gq[2], pq[2], mq[2], vq[2];
+          size_t off[2];
+          bool in[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int R = (ib * 2 + u) * 4 + (lane >> 4), q = lane & 15;
+            gq[u] = *reinterpret_cast<const f32x4*>(&wl[R * 256 + (((q ^ (R >> 2)) & 15) << 4)]);
+            in[u] = crow + ha * 64 + R < p.M && ccol + q * 4 < p.N;
+            off[u] = in[u] ? (size_t)(crow + ha * 64 + R) * p.ldc + ccol + q * 4 : 0;
+            pq[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.opt_p + off[u]));
+            if (adam) {
+              mq[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.opt_m + off[u]));
+              vq[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.opt_v + off[u]));
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (adam) {
+                float a = pq[u][e], b = mq[u][e], c = vq[u][e];
+                const float g1 = gq[u][e] * 1.0f;
+                b = p.opt_b1 * b + (1.f - p.opt_b1) * g1;
+                c = p.opt_b2 * c + (1.f - p.opt_b2) * g1 * g1;
+                a -= lr_t * b / (sqrtf(c) + eps_t);
+                pq[u][e] = a; mq[u][e] = b; vq[u][e] = c;
+              } else {
+                pq[u][e] -= lr_t * gq[u][e];
+              }
+            }
+            const unsigned w01 = (unsigned)pp_f2bf(pq[u][0]) | ((unsigned)pp_f2bf(pq[u][1]) << 16);
+            const unsigned w23 = (unsigned)pp_f2bf(pq[u][2]) | ((unsigned)pp_f2bf(pq[u][3]) << 16);
+            if (in[u]) {
+              __builtin_nontemporal_store(pq[u], reinterpret_cast<f32x4*>(p.opt_p + off[u]));
+              if (adam) {
+                __builtin_nontemporal_store(mq[u], reinterpret_cast<f32x4*>(p.opt_m + off[u]));
+                __builtin_nontemporal_store(vq[u], reinterpret_cast<f32x4*>(p.opt_v + off[u]));
+              }
+              if (p.opt_w) *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.opt_w) + off[u]) = make_uint2(w01, w23);
+            }
+          }
+        }
       }
     }
   } else {
@@ -341,6 +402,12 @@ bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a) {
   if ((reinterpret_cast<uintptr_t>(a.C) & 15) || (a.ldc & (a.epilogue == EPI_WGRAD ? 3 : 7))) return false;
   if (a.Ct && ((a.ldct & 7) || (reinterpret_cast<uintptr_t>(a.Ct) & 15))) return false;
   if (a.maskT && (reinterpret_cast<uintptr_t>(a.maskT) & 7)) return false;
+  if (a.opt_p) {
+    if (a.epilogue != EPI_WGRAD || (a.opt_m == nullptr) != (a.opt_v == nullptr)) return false;
+    if ((reinterpret_cast<uintptr_t>(a.opt_p) & 15) || (a.opt_m && ((reinterpret_cast<uintptr_t>(a.opt_m) | reinterpret_cast<uintptr_t>(a.opt_v)) & 15))) return false;
+    if (a.opt_w && (reinterpret_cast<uintptr_t>(a.opt_w) & 7)) return false;
+    if (a.opt_wt) return false;               // the transposed copy is a separate pass over the compute-dtype copy
+  }
   return true;
 }
 
@@ -350,7 +417,10 @@ int dtf_gemm_pingpong_launch(const DtfGemmArgs& a, hipStream_t s) {
   switch (a.epilogue) {
     case EPI_FWD: hipLaunchKernelGGL(gemm_pp_kernel<EPI_FWD>, grid, block, 0, s, a); break;
     case EPI_BWD: hipLaunchKernelGGL(gemm_pp_kernel<EPI_BWD>, grid, block, 0, s, a); break;
-    case EPI_WGRAD: hipLaunchKernelGGL(gemm_pp_kernel<EPI_WGRAD>, grid, block, 0, s, a); break;
+    case EPI_WGRAD:
+      if (a.opt_p) hipLaunchKernelGGL(gemm_pp_kernel<EPI_WGRAD_OPT>, grid, block, 0, s, a);
+      else hipLaunchKernelGGL(gemm_pp_kernel<EPI_WGRAD>, grid, block, 0, s, a);
+      break;
     default: return DTF_ERR_ARG;
   }
   return dtf_check_launch();

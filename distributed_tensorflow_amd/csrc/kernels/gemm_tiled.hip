@@ -338,6 +338,8 @@ static int launch_tiled(const DtfGemmArgs& a, hipStream_t s) {
     const char* e = getenv("DTF_GEMM_PINGPONG");
     g_pingpong_mode = e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)) : 2;
   }
+  if (a.opt_p)      // the folded optimizer exists in the 8-wave kernel only: the caller asked for exactly that
+    return (sizeof(T) == 2 && dtf_gemm_pingpong_takes(a)) ? dtf_gemm_pingpong_launch(a, s) : (int)DTF_ERR_SHAPE;
   if (sizeof(T) == 2 && g_pingpong_mode && dtf_gemm_pingpong_takes(a) && (g_pingpong_mode == 1 || fits))
     return dtf_gemm_pingpong_launch(a, s);
   if (sizeof(T) == 2 && (g_big_tile_mode == 1 || (g_big_tile_mode == 2 && fits && suited))) return launch_tiled_as<T, 8, 8>(a, s);
@@ -369,6 +371,7 @@ DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s) {
   if (a->Ct && a->ldct < a->M) return DTF_ERR_SHAPE;
   if (a->C32 && a->ldc32 < a->N) return DTF_ERR_SHAPE;
   if (a->epilogue == EPI_WGRAD && (a->Ct || a->C32)) return DTF_ERR_ARG;
+  if (a->opt_p && a->epilogue != EPI_WGRAD) return DTF_ERR_ARG;
   return a->dtype == 1 ? launch_tiled<unsigned short>(*a, s) : launch_tiled<unsigned int>(*a, s);
 }
 
@@ -440,6 +443,44 @@ __global__ __launch_bounds__(256) void gather_cast_transpose_kernel(const float*
         if (r + j < M) d[j] = o[j];
     }
   }
+}
+
+// dstT[c][r] = src[r][c] for 2-byte elements (the transposed compute copy of weights whose straight copy the
+// weight-gradient epilogue has just written).  64x64 tiles through LDS, 16-byte global accesses on both sides.
+__global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dstT,
+                                                          int M, int N, int lds_, int ldt) {
+  __shared__ unsigned short tile[64][72];           // 144-byte rows: 16-byte aligned, column reads spread over banks
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = t + 256 * i, rr = id >> 3, ch = id & 7;          // row, 16-byte chunk of 8 columns
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r0 + rr < M && c0 + ch * 8 < N) v = *reinterpret_cast<const u32x4*>(src + (size_t)(r0 + rr) * lds_ + c0 + ch * 8);
+    *reinterpret_cast<u32x4*>(&tile[rr][ch * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = t + 256 * i, cc = id >> 3, ch = id & 7;          // output row (a source column), chunk of 8 source rows
+    if (c0 + cc >= N || r0 + ch * 8 >= M) continue;
+    unsigned short e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = tile[ch * 8 + k][cc];
+    u32x4 v = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+               (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+    *reinterpret_cast<u32x4*>(dstT + (size_t)(c0 + cc) * ldt + r0 + ch * 8) = v;
+  }
+}
+
+DTF_EXPORT int dtf_transpose16(const void* src, void* dstT, int M, int N, int lds_, int ldt, hipStream_t s) {
+  if (!src || !dstT) return DTF_ERR_ARG;
+  if (M <= 0 || N <= 0 || (M & 7) || (N & 7) || lds_ < N || ldt < M || (lds_ & 7) || (ldt & 7)) return DTF_ERR_SHAPE;
+  if (!dtf_aligned16(src) || !dtf_aligned16(dstT)) return DTF_ERR_ALIGN;
+  if (dtf_cdiv(M, 64) > 65535) return DTF_ERR_SHAPE;
+  hipLaunchKernelGGL(transpose16_kernel, dim3(dtf_cdiv(N, 64), dtf_cdiv(M, 64)), dim3(256), 0, s,
+                     static_cast<const unsigned short*>(src), static_cast<unsigned short*>(dstT), M, N, lds_, ldt);
+  return dtf_check_launch();
 }
 
 DTF_EXPORT int dtf_gather_cast_transpose(const float* src, const int* rows, void* dst, void* dstT, int M, int N, int lds_,

@@ -55,6 +55,7 @@ class WideMLPProgram(MLPProgram):
         self.w_t = [z(dims[i + 1], dims[i]) for i in range(len(hidden))]
         self.refresh_compute_copies()
         self.grad_ready = None              # engine hook: called with a bucket index of grad_groups()
+        self.folded = [False] * len(hidden)  # layers whose weight-gradient epilogue applies the optimizer itself
         del self.schedule_tail_entries      # this program enqueues op by op; the engine then uses after_compute
 
     def grad_groups(self):
@@ -71,12 +72,44 @@ class WideMLPProgram(MLPProgram):
         wgrad = ops.build_wgrad_args(items, lr=None, tail=self._tail(q))
         return {"head": head, "wgrad": wgrad, "items": items}
 
-    def refresh_compute_copies(self) -> None:
+    def refresh_compute_copies(self, skip_folded: bool = False) -> None:
         """After an update of the fp32 master weights: rewrite W (compute dtype) and W^T."""
         st = self.state
         for l, name in enumerate(self.names):
+            if skip_folded and self.folded[l]:
+                continue                    # kept current by the weight-gradient epilogue of the previous step
             master = st.var(f"{name}_w")
             ops.gather_cast_transpose(master, None, self.w[l], self.w_t[l])
+
+    def enable_folded_optimizer(self):
+        """One worker, bf16: the weight-gradient products that run on the 8-wave kernel apply the optimizer in their
+        epilogue (master weights and moments read and written once, the gradient never stored, the compute copy
+        refreshed in place).  Returns the flat ranges the engine still has to update (biases, the layers whose
+        product is too small for that kernel, the output layer)."""
+        st = self.state
+        if st.world_size != 1 or self.cdtype != torch.bfloat16 or not self.is_cuda:
+            raise ValueError("the folded optimizer needs one worker and the bf16 GPU pipeline")
+        for l in range(len(self.names)):
+            M, N, K = self.dims[l], self.dims[l + 1], self.B
+            blocks = -(-M // 256) * -(-N // 256)
+            self.folded[l] = (ops.gemm_pingpong_takes(M, N, K) and blocks >= 192 and (M % 256 == 0 or M >= 2048)
+                              and (N % 256 == 0 or N >= 2048))
+        self._graphs.clear()
+        ranges, lo = [], 0
+        for l, name in enumerate(self.names):
+            if self.folded[l]:
+                off = st.layout.offsets[f"{name}_w"]
+                if off > lo:
+                    ranges.append((lo, off))
+                lo = off + st.var(f"{name}_w").numel()
+                lo = (lo + 3) // 4 * 4
+        if lo < st.layout.total:
+            ranges.append((lo, st.layout.total))
+        return ranges
+
+    def start(self) -> None:
+        super().start()
+        self.refresh_compute_copies()       # the masters may have been initialised or restored since construction
 
     def _weight(self, l: int) -> torch.Tensor:
         return self.w[l] if self.w[l] is not None else self.state.var(f"{self.names[l]}_w")
@@ -86,7 +119,7 @@ class WideMLPProgram(MLPProgram):
         st, B, L = self.state, self.B, len(self.names)
         rows = self.ridx[q]
         # the master weights may have been written since the last step (optimizer, all-gather, an async pull)
-        self.refresh_compute_copies()
+        self.refresh_compute_copies(skip_folded=True)
         ops.gather_cast_transpose(self.data.images, rows, self.xb, self.xb_t, m=B)
         x = self.xb
         for l, name in enumerate(self.names):
@@ -107,7 +140,21 @@ class WideMLPProgram(MLPProgram):
         early = self.grad_ready is not None and self.w[0] is not None
         for l in range(L - 1, -1, -1):
             a_t = self.xb_t if l == 0 else self.h_t[l - 1]
-            ops.gemm_nt(a_t, self.dzc_t[l], st.grad(f"{self.names[l]}_w"), ops.EPI_WGRAD,
+            wname = f"{self.names[l]}_w"
+            if self.folded[l]:
+                # the epilogue below rewrites W_l: the backward product that reads it goes first
+                if l > 0:
+                    ops.gemm_nt(self.dzc[l], self._weight(l), self.dzc[l - 1], ops.EPI_BWD, mask=self.h[l - 1],
+                                mask_t=self.h_t[l - 1], out_t=self.dzc_t[l - 1], m=B)
+                adam = st.optimizer != "sgd"
+                opt = ops.FoldedOptimizer(st.var(wname), st._view(st.m, wname) if adam else None,
+                                          st._view(st.v, wname) if adam else None, self.w[l], st.lr, st.beta1, st.beta2,
+                                          st.eps, st.state[2:3], 1)
+                ops.gemm_nt(a_t, self.dzc_t[l], st.grad(wname), ops.EPI_WGRAD, bias_out=st.grad(f"{self.names[l]}_b"),
+                            opt=opt)
+                ops.transpose16(self.w[l], self.w_t[l])
+                continue
+            ops.gemm_nt(a_t, self.dzc_t[l], st.grad(wname), ops.EPI_WGRAD,
                         bias_out=st.grad(f"{self.names[l]}_b"))
             if early:
                 self.grad_ready(l)

@@ -417,14 +417,33 @@ def _dtype_code(t):
     raise ValueError(f"tiled GEMM supports float32 and bfloat16, got {t.dtype}")
 
 
+class FoldedOptimizer:
+    """What the weight-gradient epilogue needs to apply the optimizer itself (one worker, no aggregation):
+    master weights ``p`` (and Adam moments ``m``, ``v``; both None = SGD) shaped like the gradient, the compute-dtype
+    copy ``w`` to refresh, the device step counter (``step_tensor[0] + step_offset`` = number of this update)."""
+
+    def __init__(self, p, m=None, v=None, w=None, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, step_tensor=None,
+                 step_offset=0):
+        self.p, self.m, self.v, self.w = p, m, v, w
+        self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
+        self.step_tensor, self.step_offset = step_tensor, step_offset
+
+
+def gemm_pingpong_takes(M: int, N: int, K: int) -> bool:
+    """Shapes the 8-wave kernel accepts (multiples of 8, K >= 256); mirrors ``dtf_gemm_pingpong_takes``."""
+    return M % 8 == 0 and N % 8 == 0 and K % 8 == 0 and K >= 256
+
+
 def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t=None, out_f32=None, bias_out=None,
-            m=None, mask_t=None):
+            m=None, mask_t=None, opt=None):
     """``out[:m] = epilogue(a[:m] @ b^T)`` with ``a`` [M,K] and ``b`` [N,K], both k-contiguous.
 
     forward: ``+bias``, ReLU, optional transposed copy ``out_t`` [N,M] and fp32 copy ``out_f32``;
     backward: zero where ``mask <= 0`` (``mask_t``: the same mask transposed, [N, >=M], read with wide loads
     when given), optional ``out_t``;
-    weight gradient: ``out`` is fp32, ``bias_out[n] = sum_k b[n,k]``.
+    weight gradient: ``out`` is fp32, ``bias_out[n] = sum_k b[n,k]``; with ``opt`` (a ``FoldedOptimizer``) the
+    gradient is not stored: the epilogue updates ``opt.p`` (and moments) and refreshes ``opt.w`` (bf16, 8-wave
+    kernel only; the call fails if the shape is outside that kernel's range).
     """
     M = m if m is not None else a.shape[0]
     N, K = b.shape
@@ -444,6 +463,16 @@ def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t
         else:
             if bias_out is not None:
                 bias_out.copy_(b.float().sum(1))
+            if opt is not None:
+                g = c.contiguous()
+                if opt.m is None:
+                    sgd_apply(opt.p, g, opt.lr)
+                else:
+                    adam_apply(opt.p, g, opt.m, opt.v, opt.lr, opt.beta1, opt.beta2, opt.eps, 1.0,
+                               step_tensor=opt.step_tensor, step_offset=opt.step_offset)
+                if opt.w is not None:
+                    opt.w.copy_(opt.p.to(opt.w.dtype))
+                return out
         out[:M].copy_(c.to(out.dtype))
         if out_t is not None:
             out_t[:, :M].copy_(c.t().to(out_t.dtype))
@@ -477,8 +506,46 @@ def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t
                          relu=int(bool(relu)), epilogue=epilogue, dtype=_dtype_code(a), a_bytes=_lib.span_bytes(a),
                          b_bytes=_lib.span_bytes(b), maskT=_lib.ptr(mask_t), ldmaskt=0 if mask_t is None else mask_t.stride(0),
                          pad_=0)
+    if opt is not None:
+        if epilogue != EPI_WGRAD or a.dtype != torch.bfloat16 or M != a.shape[0]:
+            raise ValueError("gemm_nt: the folded optimizer belongs to a bf16 weight-gradient product")
+        for name, t in (("p", opt.p), ("m", opt.m), ("v", opt.v)):
+            if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (M, N) or t.stride(0) != out.stride(0)
+                                  or t.stride(1) != 1):
+                raise ValueError(f"gemm_nt: opt.{name} must be float32 [{M},{N}] laid out like the gradient")
+        if (opt.m is None) != (opt.v is None):
+            raise ValueError("gemm_nt: Adam needs both moments")
+        if opt.w is not None and (opt.w.dtype != a.dtype or tuple(opt.w.shape) != (M, N) or opt.w.stride(0) != out.stride(0)):
+            raise ValueError("gemm_nt: opt.w must be the compute-dtype copy, laid out like the gradient")
+        if opt.m is not None and opt.step_tensor is None:
+            raise ValueError("gemm_nt: Adam reads its step number from a device counter")
+        _same_device(a, opt.p, opt.m, opt.v, opt.w, opt.step_tensor)
+        args.opt_p, args.opt_m, args.opt_v = opt.p.data_ptr(), _lib.ptr(opt.m), _lib.ptr(opt.v)
+        args.opt_w, args.opt_wt, args.ldwt = _lib.ptr(opt.w), None, 0
+        args.opt_step = None if opt.step_tensor is None else _i32c(opt.step_tensor, "step_tensor").data_ptr()
+        args.opt_step_offset = int(opt.step_offset)
+        args.opt_lr, args.opt_b1, args.opt_b2, args.opt_eps = float(opt.lr), float(opt.beta1), float(opt.beta2), float(opt.eps)
     _lib.check(_lib.kernels().dtf_gemm_tiled(C.byref(args), _lib.stream_handle()), "gemm_nt")
     return out
+
+
+def transpose16(src, dst_t):
+    """``dst_t[c, r] = src[r, c]`` for 2-byte elements (bf16): the transposed compute copy of weights."""
+    M, N = src.shape
+    if src.dtype != dst_t.dtype or src.element_size() != 2 or tuple(dst_t.shape[:1]) != (N,) or dst_t.shape[1] < M:
+        raise ValueError("transpose16: dst_t must be [N, >=M] of the same 2-byte dtype")
+    if not src.is_cuda:
+        dst_t[:, :M].copy_(src.t())
+        return dst_t
+    _same_device(src, dst_t)
+    if src.stride(1) != 1 or dst_t.stride(1) != 1:
+        raise ValueError("transpose16: operands must be row-major")
+    lib = _lib.kernels()
+    lib.dtf_transpose16.restype = C.c_int
+    lib.dtf_transpose16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    _lib.check(lib.dtf_transpose16(src.data_ptr(), dst_t.data_ptr(), M, N, src.stride(0), dst_t.stride(0), _lib.stream_handle()),
+               "transpose16")
+    return dst_t
 
 
 def gemm_set_modes(big_tile: int = -1, pingpong: int = -1) -> None:

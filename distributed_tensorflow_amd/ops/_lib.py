@@ -69,7 +69,10 @@ class GemmArgs(C.Structure):
                 ("bias", C.c_void_p), ("mask", C.c_void_p), ("bias_out", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
                 ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ldct", C.c_int), ("ldc32", C.c_int),
                 ("ldmask", C.c_int), ("relu", C.c_int), ("epilogue", C.c_int), ("dtype", C.c_int), ("a_bytes", C.c_uint),
-                ("b_bytes", C.c_uint), ("maskT", C.c_void_p), ("ldmaskt", C.c_int), ("pad_", C.c_int)]
+                ("b_bytes", C.c_uint), ("maskT", C.c_void_p), ("ldmaskt", C.c_int), ("pad_", C.c_int),
+                ("opt_p", C.c_void_p), ("opt_m", C.c_void_p), ("opt_v", C.c_void_p), ("opt_w", C.c_void_p),
+                ("opt_wt", C.c_void_p), ("opt_step", C.c_void_p), ("opt_step_offset", C.c_int), ("ldwt", C.c_int),
+                ("opt_lr", C.c_float), ("opt_b1", C.c_float), ("opt_b2", C.c_float), ("opt_eps", C.c_float)]
 
 
 WLOG_INTS = 64

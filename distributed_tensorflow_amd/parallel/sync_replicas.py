@@ -104,7 +104,15 @@ class SyncReplicasEngine:
             # against 2.73 ms per wide-MLP step, the 8-wave GEMM leaves no registers for a second kernel's waves
             overlap_local = (not self.use_coll and state.device.type == "cuda" and hasattr(program, "grad_groups")
                              and state.nbytes() >= BUCKETED_ABOVE_BYTES and os.environ.get("DTF_OVERLAP_UPDATE", "0") == "1")
-            if self.collective == "bucketed" or overlap_local:
+            fold = (not self.use_coll and self.world == 1 and state.device.type == "cuda"
+                    and hasattr(program, "enable_folded_optimizer") and getattr(program, "cdtype", None) == torch.bfloat16
+                    and os.environ.get("DTF_FOLD_OPTIMIZER", "1") != "0" and not overlap_local)
+            if fold:
+                # one worker: the big weight-gradient products update their weights in the epilogue; the rest here
+                rest = program.enable_folded_optimizer()
+                self.folded_ranges = rest
+                program.after_compute = lambda: state.apply_ranges(rest)
+            elif self.collective == "bucketed" or overlap_local:
                 self._install_bucketed(group)
             elif state.device.type == "cuda":
                 self._install_native_update(group)

@@ -79,3 +79,25 @@ def test_gpu_wide_pipeline_is_identical_on_both_gemm_kernels():
     assert out[1][1] == out[0][1]
     assert torch.equal(out[1][0], out[0][0])
     assert out[1][1][-1] < out[1][1][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_gpu_folded_optimizer_matches_the_separate_update(optimizer, monkeypatch):
+    """One worker: the 4096x4096 weight-gradient product applies the optimizer in its epilogue (gradient never
+    stored, master/moments touched once, compute copy refreshed, transposed copy rebuilt from it).  Same arithmetic
+    element for element as the flat optimizer kernel: the trajectory must not differ by a bit."""
+    out = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("DTF_FOLD_OPTIMIZER", fold)
+        _, st, prog = _run(WideMLPProgram, "cuda", 6, optimizer, 1e-3 if optimizer == "adam" else 0.05,
+                           hidden=[4096, 4096], batch=256, dtype=torch.bfloat16)
+        torch.cuda.synchronize()
+        assert any(prog.folded) == (fold == "1") and not prog.folded[0]
+        out[fold] = (st.params.clone(), [r.loss for r in prog.read_log(0, 6)],
+                     None if st.m is None else (st.m.clone(), st.v.clone()))
+    assert out["1"][1] == out["0"][1]
+    assert torch.equal(out["1"][0], out["0"][0])
+    if optimizer == "adam":
+        assert torch.equal(out["1"][2][0], out["0"][2][0]) and torch.equal(out["1"][2][1], out["0"][2][1])
+    assert out["1"][1][-1] < out["1"][1][0]
