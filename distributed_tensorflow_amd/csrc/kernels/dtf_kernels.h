@@ -285,6 +285,16 @@ DTF_EXPORT int dtf_step_tail(const DtfTailArgs* a, int init_only, hipStream_t s)
 
 // flat fused optimizers (shard updates)
 DTF_EXPORT int dtf_sgd_apply(float* param, const float* grad, int64_t n, float lr, float grad_scale, hipStream_t s);
+#define DTF_MAX_OPT_RANGES 16
+struct DtfOptRangesArgs {
+  float* p; const float* g; float* m; float* v;      // flat buffers; m, v null = SGD
+  const int* step_ptr;                               // Adam: number of this update = *step_ptr + step_offset
+  long long lo[DTF_MAX_OPT_RANGES], hi[DTF_MAX_OPT_RANGES];   // element ranges, multiples of 4
+  int nranges, step_offset;
+  float lr, b1, b2, eps, gscale;
+  int pad_;
+};
+DTF_EXPORT int dtf_opt_ranges(const DtfOptRangesArgs* a, hipStream_t s);
 DTF_EXPORT int dtf_adam_apply(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                               float beta2, float eps, float grad_scale, const int* step_ptr, int step_offset,
                               hipStream_t s);

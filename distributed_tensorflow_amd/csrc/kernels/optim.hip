@@ -112,6 +112,49 @@ DTF_EXPORT int dtf_adam_apply(float* param, const float* grad, float* m, float* 
   return dtf_check_launch();
 }
 
+// The optimizer over up to DTF_MAX_OPT_RANGES ranges [lo, hi) of one flat buffer in ONE launch (the pieces the
+// weight-gradient epilogues leave over: biases, small layers): blockIdx.y = range.  Same arithmetic as above.
+__global__ __launch_bounds__(256) void opt_ranges_kernel(DtfOptRangesArgs a) {
+  const int64_t lo = a.lo[blockIdx.y], n4 = (a.hi[blockIdx.y] - lo) >> 2;
+  f32x4* p4 = reinterpret_cast<f32x4*>(a.p + lo);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(a.g + lo);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (!a.m) {
+    const float step = a.lr * a.gscale;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) p4[i] = p4[i] - step * g4[i];
+    return;
+  }
+  const int t = (a.step_ptr ? *a.step_ptr : 0) + a.step_offset;
+  const float bc1 = 1.f - powf(a.b1, (float)t), bc2 = 1.f - powf(a.b2, (float)t);
+  const float sq = sqrtf(bc2);
+  const float lr_t = a.lr * sq / bc1, eps_t = a.eps * sq;
+  f32x4* m4 = reinterpret_cast<f32x4*>(a.m + lo);
+  f32x4* v4 = reinterpret_cast<f32x4*>(a.v + lo);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = p4[i], gv = g4[i], mv = m4[i], vv = v4[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float x = pv[k], y = mv[k], z = vv[k];
+      adam_one(x, gv[k] * a.gscale, y, z, lr_t, a.b1, a.b2, eps_t);
+      pv[k] = x; mv[k] = y; vv[k] = z;
+    }
+    p4[i] = pv; m4[i] = mv; v4[i] = vv;
+  }
+}
+
+DTF_EXPORT int dtf_opt_ranges(const DtfOptRangesArgs* a, hipStream_t s) {
+  if (!a || !a->p || !a->g || (a->m == nullptr) != (a->v == nullptr)) return DTF_ERR_ARG;
+  if (a->nranges <= 0 || a->nranges > DTF_MAX_OPT_RANGES) return DTF_ERR_SHAPE;
+  if (!dtf_aligned16(a->p) || !dtf_aligned16(a->g) || (a->m && (!dtf_aligned16(a->m) || !dtf_aligned16(a->v)))) return DTF_ERR_ALIGN;
+  int64_t longest = 0;
+  for (int i = 0; i < a->nranges; ++i) {
+    if (a->lo[i] < 0 || a->hi[i] <= a->lo[i] || (a->lo[i] & 3) || (a->hi[i] & 3)) return DTF_ERR_SHAPE;
+    if (a->hi[i] - a->lo[i] > longest) longest = a->hi[i] - a->lo[i];
+  }
+  hipLaunchKernelGGL(opt_ranges_kernel, dim3(stream_grid(longest >> 2, 256), a->nranges), dim3(256), 0, s, *a);
+  return dtf_check_launch();
+}
+
 // dst = alpha * dst + beta * src   (gradient accumulation over several rounds, R > num_workers)
 __global__ __launch_bounds__(256) void accumulate_kernel(float* __restrict__ d, const float* __restrict__ s, int64_t n,
                                                          float alpha, float beta) {

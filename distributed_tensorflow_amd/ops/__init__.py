@@ -381,6 +381,34 @@ def adam_apply(param, grad, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_sca
     return param
 
 
+def optimizer_ranges(params, grads, ranges, lr, m=None, v=None, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0,
+                     step_tensor=None, step_offset=0):
+    """SGD (``m`` and ``v`` None) or Adam over the element ranges ``[(lo, hi), ...]`` of one flat buffer, one launch
+    on the GPU; the same arithmetic as ``sgd_apply`` / ``adam_apply``."""
+    if not params.is_cuda or len(ranges) > _lib.MAX_OPT_RANGES or any((lo | hi) & 3 for lo, hi in ranges):
+        for lo, hi in ranges:
+            if m is None:
+                sgd_apply(params[lo:hi], grads[lo:hi], lr, grad_scale)
+            else:
+                adam_apply(params[lo:hi], grads[lo:hi], m[lo:hi], v[lo:hi], lr, beta1, beta2, eps, grad_scale,
+                           step_tensor=step_tensor, step_offset=step_offset)
+        return params
+    _same_device(params, grads, m, v, step_tensor)
+    a = _lib.OptRangesArgs(p=_f32c(params, "params").data_ptr(), g=_f32c(grads, "grads").data_ptr(), m=_lib.ptr(m),
+                           v=_lib.ptr(v), step_ptr=None if step_tensor is None else _i32c(step_tensor, "step").data_ptr(),
+                           nranges=len(ranges), step_offset=step_offset, lr=lr, b1=beta1, b2=beta2, eps=eps,
+                           gscale=grad_scale, pad_=0)
+    for i, (lo, hi) in enumerate(ranges):
+        if not 0 <= lo < hi <= params.numel():
+            raise ValueError("optimizer_ranges: range outside the buffer")
+        a.lo[i], a.hi[i] = lo, hi
+    lib = _lib.kernels()
+    lib.dtf_opt_ranges.restype = C.c_int
+    lib.dtf_opt_ranges.argtypes = [C.POINTER(_lib.OptRangesArgs), C.c_void_p]
+    _lib.check(lib.dtf_opt_ranges(C.byref(a), _lib.stream_handle()), "optimizer_ranges")
+    return params
+
+
 def accumulate(dst, src, alpha=1.0, beta=1.0):
     """``dst = alpha*dst + beta*src`` (gradient accumulation across rounds)."""
     if dst.numel() != src.numel():

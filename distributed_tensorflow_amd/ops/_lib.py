@@ -78,6 +78,16 @@ class GemmArgs(C.Structure):
 WLOG_INTS = 64
 
 
+MAX_OPT_RANGES = 16
+
+
+class OptRangesArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step_ptr", C.c_void_p),
+                ("lo", C.c_longlong * MAX_OPT_RANGES), ("hi", C.c_longlong * MAX_OPT_RANGES), ("nranges", C.c_int),
+                ("step_offset", C.c_int), ("lr", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float),
+                ("gscale", C.c_float), ("pad_", C.c_int)]
+
+
 class Mlp2Peer(C.Structure):
     """Mirror of ``DtfMlp2Peer``: peers' gradient slots and arrival flags for the in-launch exchange."""
     _fields_ = [("slot", C.c_void_p * 8), ("wgflags", C.c_void_p * 8), ("err", C.c_void_p), ("rank", C.c_int),

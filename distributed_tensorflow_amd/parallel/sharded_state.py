@@ -201,13 +201,8 @@ class ShardedState:
         e.g. inside the weight-gradient epilogues); advances the update counter once."""
         if self.world_size != 1:
             raise ValueError("apply_ranges is the one-worker path")
-        for lo, hi in ranges:
-            p, g = self.params[lo:hi], self.grads[lo:hi]
-            if self.optimizer == "sgd":
-                ops.sgd_apply(p, g, self.lr, grad_scale)
-            else:
-                ops.adam_apply(p, g, self.m[lo:hi], self.v[lo:hi], self.lr, self.beta1, self.beta2, self.eps, grad_scale,
-                               step_tensor=self.state[2:3], step_offset=1)
+        ops.optimizer_ranges(self.params, self.grads, list(ranges), self.lr, self.m, self.v, self.beta1, self.beta2, self.eps,
+                             grad_scale, step_tensor=self.state[2:3], step_offset=1)
         if self.optimizer != "sgd":
             self.state[2:3].add_(1)
 
