@@ -242,6 +242,7 @@ __device__ __forceinline__ void mlp2_stat_block(const DtfMlp2Args& p, int rb, in
 
 // Tail workgroup tb: counters (tb == 0) and rows [8*tb, 8*tb+8) of the next step's batch: 32 threads per row
 // copy the image row into the next Xg slot, the label row into the next labg slot, the index into ridx.
+template <int MODE>
 __device__ __forceinline__ void mlp2_tail_block(const DtfMlp2Args& p, int tb) {
   const DtfTailArgs& t = p.tail;
   const int tid = threadIdx.x;
@@ -255,7 +256,7 @@ __device__ __forceinline__ void mlp2_tail_block(const DtfMlp2Args& p, int tb) {
     int* rec = p.wlog + (size_t)DTF_WLOG_INTS * (ls % p.log_cap);
     rec[0] = gs;       // value of global_step before this step's increment
     rec[1] = ls;
-    if (p.mode == 3) {
+    if (MODE == 3) {
       // the ps-side counters: global_step next to shard 0, one "updates applied" counter per shard
       const int g2 = __hip_atomic_fetch_add(p.async_.counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
       for (int s = 0; s < p.async_.shards; ++s)
@@ -360,7 +361,9 @@ __device__ __forceinline__ int dz_slot(int c) { return 4 * (c & 3) + (c >> 2); }
 
 // One weight-gradient tile per wave.  IS2 = false: tiles of dW1 (inputs x hidden), dz1 rebuilt in registers;
 // IS2 = true: tiles of dW2 (hidden x classes).  `tile0` is the first tile of this workgroup within its kind.
-template <int NJ, int NRB, bool IS2>
+// MODE (compile time, = DtfMlp2Args.mode): the exchange / push code of modes 2 and 3 must not cost the plain
+// modes registers or instructions (measured: 0.3 us per step when `mode` was a run-time branch).
+template <int NJ, int NRB, bool IS2, int MODE>
 __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0, int Rp, unsigned zbytes, float* dzs,
                                                  int wgid, int* peer_timeout) {
   constexpr int CP = 4 * NJ;                        // classes padded to whole MFMA k-steps
@@ -427,7 +430,7 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
   }
   float* mptr[4] = {nullptr, nullptr, nullptr, nullptr};
   float* mbptr = nullptr;
-  if (p.mode == 3) {
+  if (MODE == 3) {
     // master values of this tile, requested now: the (possibly remote) read overlaps the whole launch
     const long long slice = p.async_.slice;
     const long long wbase = (long long)(Wt - p.async_.params_base), bbase = (long long)(bt - p.async_.params_base);
@@ -446,11 +449,11 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     bold = __builtin_nontemporal_load(mbptr);
   }
   int seq = 0;
-  if (p.mode == 2) {
+  if (MODE == 2) {
     seq = p.ctr_snap[1] + 1;                        // number of this step, the same on every rank
     if (tid == 0) *peer_timeout = 0;
   }
-  if (p.mode == 1 || p.mode == 2) {
+  if (MODE == 1 || MODE == 2) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 4 * g + r;
@@ -472,7 +475,7 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
   M2_STAMP(4, blockIdx.x);
   // (mode 2: waves without a tile go on to the barriers of the exchange; their loads are out of range, i.e. zero,
   // and every store below is guarded)
-  if (!has_tile && p.mode != 2) return;
+  if (!has_tile && MODE != 2) return;
 
   // ---- the tile ----
   float bq[NRB][4];
@@ -518,7 +521,7 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     bsum += __shfl_xor(bsum, 32);
   }
   const bool b_lane = mt == 0 && g == 0 && bn_ok;
-  if (p.mode == 2) {
+  if (MODE == 2) {
     // ---- exchange with the same workgroup of every peer, then the averaged update ----
     const int me = p.peer.rank, world = p.peer.world;
     size_t woff[4];
@@ -528,10 +531,12 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
       const int row = m0 + 4 * g + r;
       wok[r] = row < Mo && bn_ok;
       woff[r] = wok[r] ? (size_t)(dWt - p.peer.slot[me]) + (size_t)row * N + n0 + fr : 0;
-      if (wok[r]) dWt[(size_t)row * N + n0 + fr] = gv[r];
+      // system-scope stores (write-through past every cache and write buffer of this XCD): their acknowledgement,
+      // awaited below, then means "in memory", which is what a peer - another GPU, or another XCD - reads
+      if (wok[r]) __hip_atomic_store(&dWt[(size_t)row * N + n0 + fr], gv[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const size_t boff = b_lane ? (size_t)(dbt - p.peer.slot[me]) + n0 + fr : 0;
-    if (b_lane) dbt[n0 + fr] = bsum;
+    if (b_lane) __hip_atomic_store(&dbt[n0 + fr], bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // The slots and flags are uncached memory: a store is in memory (not in a cache) once it is acknowledged, so
     // "acknowledged, then barrier, then flag" publishes the tile.  No system-scope fence: it would write back and
     // invalidate the whole L2 once per workgroup, under the other workgroups' feet.
@@ -567,8 +572,8 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
       for (int k = 0; k < 8; ++k) {
         const float* src = p.peer.slot[k < world ? k : me];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pv[k][r] = __builtin_nontemporal_load(src + woff[r]);
-        pb[k] = __builtin_nontemporal_load(src + boff);
+        for (int r = 0; r < 4; ++r) pv[k][r] = __hip_atomic_load(src + woff[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        pb[k] = __hip_atomic_load(src + boff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     float sv[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
@@ -591,11 +596,11 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     const int row = m0 + 4 * g + r;
     if (row < Mo && bn_ok) {
       const size_t off = (size_t)row * N + n0 + fr;
-      if (p.mode == 3) {
+      if (MODE == 3) {
         const float w = wold[r] - p.lr * gv[r];
         __builtin_nontemporal_store(w, mptr[r]);      // push: the master, wherever it lives
         Wt[off] = w;                                   // pull: the same value is this worker's replica
-      } else if (p.mode == 1) {
+      } else if (MODE == 1) {
         Wt[off] = wold[r] - p.lr * gv[r];
       } else {
         dWt[off] = gv[r];
@@ -603,11 +608,11 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     }
   }
   if (b_lane) {
-    if (p.mode == 3) {
+    if (MODE == 3) {
       const float w = bold - p.lr * bsum;
       __builtin_nontemporal_store(w, mbptr);
       bt[n0 + fr] = w;
-    } else if (p.mode == 1) {
+    } else if (MODE == 1) {
       bt[n0 + fr] = bold - p.lr * bsum;
     } else {
       dbt[n0 + fr] = bsum;
@@ -617,7 +622,7 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
 }
 
 // workgroups of launch 2: [0, R16) stat | nb1 blocks of dW1 tiles | nb2 blocks of dW2 tiles | ceil(B/8) tail
-template <int NJ, int NRB>
+template <int NJ, int NRB, int MODE>
 __global__ __launch_bounds__(256) void mlp2_bwd_kernel(DtfMlp2Args p) {
   __shared__ float dzs[128 * 20];
   __shared__ int peer_timeout;
@@ -627,9 +632,9 @@ __global__ __launch_bounds__(256) void mlp2_bwd_kernel(DtfMlp2Args p) {
   const unsigned zbytes = 16u * (unsigned)Rp * 8u * 4u;
   const int b = blockIdx.x;
   if (b < R16) mlp2_stat_block(p, b, Rp, zbytes);
-  else if (b < R16 + nb1) mlp2_train_block<NJ, NRB, false>(p, (b - R16) * 4, Rp, zbytes, dzs, b - R16, &peer_timeout);
-  else if (b < R16 + nb1 + nb2) mlp2_train_block<NJ, NRB, true>(p, (b - R16 - nb1) * 4, Rp, zbytes, dzs, b - R16, &peer_timeout);
-  else mlp2_tail_block(p, b - R16 - nb1 - nb2);
+  else if (b < R16 + nb1) mlp2_train_block<NJ, NRB, false, MODE>(p, (b - R16) * 4, Rp, zbytes, dzs, b - R16, &peer_timeout);
+  else if (b < R16 + nb1 + nb2) mlp2_train_block<NJ, NRB, true, MODE>(p, (b - R16 - nb1) * 4, Rp, zbytes, dzs, b - R16, &peer_timeout);
+  else mlp2_tail_block<MODE>(p, b - R16 - nb1 - nb2);
 }
 
 static int mlp2_validate(const DtfMlp2Args* a) {
@@ -679,13 +684,23 @@ DTF_EXPORT int dtf_mlp2_fwd(const DtfMlp2Args* a, hipStream_t s) {
   return dtf_check_launch();
 }
 
+template <int NJ, int MODE>
+static void mlp2_launch_bwd_mode(const DtfMlp2Args& a, int nblk, hipStream_t s) {
+  const int nrb = dtf_cdiv(a.B, 16);
+  if (nrb <= 2) hipLaunchKernelGGL((mlp2_bwd_kernel<NJ, 2, MODE>), dim3(nblk), dim3(256), 0, s, a);
+  else if (nrb <= 4) hipLaunchKernelGGL((mlp2_bwd_kernel<NJ, 4, MODE>), dim3(nblk), dim3(256), 0, s, a);
+  else if (nrb <= 7) hipLaunchKernelGGL((mlp2_bwd_kernel<NJ, 7, MODE>), dim3(nblk), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((mlp2_bwd_kernel<NJ, 8, MODE>), dim3(nblk), dim3(256), 0, s, a);
+}
+
 template <int NJ>
 static void mlp2_launch_bwd(const DtfMlp2Args& a, int nblk, hipStream_t s) {
-  const int nrb = dtf_cdiv(a.B, 16);
-  if (nrb <= 2) hipLaunchKernelGGL((mlp2_bwd_kernel<NJ, 2>), dim3(nblk), dim3(256), 0, s, a);
-  else if (nrb <= 4) hipLaunchKernelGGL((mlp2_bwd_kernel<NJ, 4>), dim3(nblk), dim3(256), 0, s, a);
-  else if (nrb <= 7) hipLaunchKernelGGL((mlp2_bwd_kernel<NJ, 7>), dim3(nblk), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((mlp2_bwd_kernel<NJ, 8>), dim3(nblk), dim3(256), 0, s, a);
+  switch (a.mode) {
+    case 0: mlp2_launch_bwd_mode<NJ, 0>(a, nblk, s); break;
+    case 1: mlp2_launch_bwd_mode<NJ, 1>(a, nblk, s); break;
+    case 2: mlp2_launch_bwd_mode<NJ, 2>(a, nblk, s); break;
+    default: mlp2_launch_bwd_mode<NJ, 3>(a, nblk, s); break;
+  }
 }
 
 DTF_EXPORT int dtf_mlp2_bwd(const DtfMlp2Args* a, hipStream_t s) {
