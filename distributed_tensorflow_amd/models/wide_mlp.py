@@ -107,9 +107,18 @@ class WideMLPProgram(MLPProgram):
             ranges.append((lo, st.layout.total))
         return ranges
 
+    def run(self, n_steps: int, graph_steps: int = 64) -> None:
+        # the host has rewritten the masters (initialise, restore, broadcast) since the copies were made: rebuild all
+        # of them here, outside any captured step (steps skip the layers whose epilogue keeps the copies current)
+        if self._started and getattr(self, "_values_seen", None) != self.state.values_version:
+            self.refresh_compute_copies()
+            self._values_seen = self.state.values_version
+        super().run(n_steps, graph_steps)
+
     def start(self) -> None:
         super().start()
         self.refresh_compute_copies()       # the masters may have been initialised or restored since construction
+        self._values_seen = self.state.values_version
 
     def _weight(self, l: int) -> torch.Tensor:
         return self.w[l] if self.w[l] is not None else self.state.var(f"{self.names[l]}_w")

@@ -122,6 +122,7 @@ class ShardedState:
         else:
             self.m = self.v = None
         self.initialized = False
+        self.values_version = 0       # bumped whenever the host rewrites the parameters (initialise, restore, broadcast)
 
     # ---- views
     def _view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
@@ -162,6 +163,7 @@ class ShardedState:
             self.m.zero_()
             self.v.zero_()
         self.initialized = True
+        self.values_version += 1
 
     def load_values(self, values: Dict[str, torch.Tensor], global_step: Optional[int] = None) -> None:
         """Inject explicit values (parity tests, checkpoint restore)."""
@@ -177,6 +179,7 @@ class ShardedState:
         if global_step is not None:
             self.state[0] = int(global_step)
         self.initialized = True
+        self.values_version += 1
 
     def named_tensors(self) -> Dict[str, torch.Tensor]:
         """Everything the reference's default Saver would write: global_step + trainable variables."""

@@ -78,6 +78,7 @@ class Supervisor:
             coll = Collectives()          # stages GPU tensors through the host on gloo rehearsal groups
             coll.broadcast(st.params, 0)
             coll.broadcast(st.state, 0)
+            st.values_version += 1
             st.initialized = True
         self._last_save = time.time()
         self._last_rate_time = time.time()

@@ -101,3 +101,18 @@ def test_gpu_folded_optimizer_matches_the_separate_update(optimizer, monkeypatch
     if optimizer == "adam":
         assert torch.equal(out["1"][2][0], out["0"][2][0]) and torch.equal(out["1"][2][1], out["0"][2][1])
     assert out["1"][1][-1] < out["1"][1][0]
+
+
+@pytest.mark.gpu
+def test_gpu_folded_layers_pick_up_restored_weights():
+    """Layers whose weight-gradient epilogue keeps the bf16 copies current are not re-cast every step; when the host
+    rewrites the masters between runs (restore, broadcast) the next run must rebuild the copies first."""
+    _, st, prog = _run(WideMLPProgram, "cuda", 3, "adam", 1e-3, hidden=[4096, 4096], batch=256, dtype=torch.bfloat16)
+    assert prog.folded[1]
+    torch.cuda.synchronize()
+    new = {n: torch.zeros_like(st.var(n)).cpu() for n in st.names()}
+    st.load_values(new)                                      # every weight zero: logits are the bias, i.e. zero
+    prog.run(2, 2)
+    torch.cuda.synchronize()
+    rec = prog.read_log(3, 1)[0]
+    assert abs(rec.loss - 2.302585) < 1e-3                   # log(10): the stale bf16 copies would give another loss
