@@ -204,3 +204,31 @@ def test_launchers_reject_bad_shapes():
     with pytest.raises(ValueError):
         ops.head(torch.zeros(4, 8, device=DEV), torch.zeros(8, 20, device=DEV), torch.zeros(20, device=DEV),
                  torch.zeros(4, 20, device=DEV), 4, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adam", [True, False])
+def test_optimizer_over_ranges_matches_the_flat_kernels(adam):
+    """One launch over several ranges of a flat buffer == the flat SGD/Adam kernels range by range, bit for bit;
+    elements outside the ranges stay untouched."""
+    import torch
+    from distributed_tensorflow_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n = 40000
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    m0, v0 = torch.rand(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.01
+    ranges = [(0, 1024), (4096, 4100), (8192, 30000), (39996, 40000)]
+    step = torch.tensor([4], dtype=torch.int32, device="cuda")
+    a = [t.cuda() for t in (p0, gr, m0, v0)]
+    b = [t.cuda() for t in (p0, gr, m0, v0)]
+    ops.optimizer_ranges(a[0], a[1], ranges, 1e-3, a[2] if adam else None, a[3] if adam else None, grad_scale=0.5,
+                         step_tensor=step, step_offset=1)
+    for lo, hi in ranges:
+        if adam:
+            ops.adam_apply(b[0][lo:hi], b[1][lo:hi], b[2][lo:hi], b[3][lo:hi], 1e-3, grad_scale=0.5, step_tensor=step,
+                           step_offset=1)
+        else:
+            ops.sgd_apply(b[0][lo:hi], b[1][lo:hi], 1e-3, 0.5)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(a[0][1024:4096].cpu(), p0[1024:4096])
