@@ -180,3 +180,39 @@ def test_pingpong_full_chip_is_bit_identical_to_the_four_wave_kernel(pingpong_ke
         got = torch.zeros(M, N, device=DEV)
         ops.gemm_nt(a, b, out, ops.EPI_FWD, out_f32=got)
         assert torch.equal(got, ref), f"repetition {rep}: {(got != ref).sum().item()} elements differ"
+
+
+@pytest.mark.parametrize("M,N", [(64, 64), (72, 200), (4096, 784), (8, 8)])
+def test_transpose16(M, N):
+    src = _rand(M, N, seed=5).to(DEV, torch.bfloat16)
+    dst = torch.zeros(N, M + 8, dtype=torch.bfloat16, device=DEV)           # wider than needed: ldt != M
+    ops.transpose16(src, dst)
+    assert torch.equal(dst[:, :M].cpu(), src.t().cpu()) and float(dst[:, M:].abs().sum()) == 0.0
+
+
+def test_folded_optimizer_epilogue_against_separate_kernels(pingpong_kernel):
+    """Weight-gradient product with the optimizer in the epilogue (ragged shape, Adam and SGD): masters, moments and
+    the bf16 copy must equal gradient product + flat optimizer kernel + cast, bit for bit."""
+    M, N, K = 520, 264, 512
+    xt, dyt = _rand(M, K, seed=1).to(DEV, torch.bfloat16), _rand(N, K, seed=2, scale=0.1).to(DEV, torch.bfloat16)
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    for adam in (True, False):
+        p0 = _rand(M, N, seed=3).to(DEV)
+        m0, v0 = _rand(M, N, seed=4).abs().to(DEV) * 0.1, _rand(M, N, seed=5).abs().to(DEV) * 0.01
+        grad, db = torch.zeros(M, N, device=DEV), torch.zeros(N, device=DEV)
+        ops.gemm_nt(xt, dyt, grad, ops.EPI_WGRAD, bias_out=db)
+        pr, mr, vr = p0.clone(), m0.clone(), v0.clone()
+        if adam:
+            ops.adam_apply(pr, grad, mr, vr, 1e-3, step_tensor=step, step_offset=1)
+        else:
+            ops.sgd_apply(pr, grad, 0.05)
+        pf, mf, vf = p0.clone(), m0.clone(), v0.clone()
+        w = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        db2, unused = torch.zeros(N, device=DEV), torch.zeros(M, N, device=DEV)
+        opt = ops.FoldedOptimizer(pf, mf if adam else None, vf if adam else None, w, 1e-3 if adam else 0.05,
+                                  step_tensor=step, step_offset=1)
+        ops.gemm_nt(xt, dyt, unused, ops.EPI_WGRAD, bias_out=db2, opt=opt)
+        assert torch.equal(pf, pr) and torch.equal(db2, db) and float(unused.abs().sum()) == 0.0
+        assert torch.equal(w, pr.to(torch.bfloat16))
+        if adam:
+            assert torch.equal(mf, mr) and torch.equal(vf, vr)
