@@ -211,9 +211,12 @@ DTF_EXPORT int dtf_small_gemm(const DtfSmallGemmArgs* a, hipStream_t s) {
 
 // CH: 16*CH batch rows per pass (row indices, then every operand load, then the MFMAs); 7 covers the reference
 // batch of 100 in one pass, 16 quarters the number of dependent passes of a 4096-row batch.
-template <int CH>
+// SPLIT: one tile per workgroup, its batch rows dealt to the four waves in quarters and the partial tiles summed
+// through LDS (wave 0 stores).  A 4096-row batch against a [4096, 10] layer is 256 tiles: four per workgroup
+// leave three quarters of the CUs idle and every wave with 16 dependent passes; split, all CUs run 4 passes.
+template <int CH, bool SPLIT>
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
-  const int nblk_tiles = (p.total_tiles + 3) >> 2;
+  const int nblk_tiles = SPLIT ? p.total_tiles : (p.total_tiles + 3) >> 2;
   if ((int)blockIdx.x >= nblk_tiles) {
     if (p.tail.enable) dtf_tail_body(p.tail, threadIdx.x, blockDim.x, false);
     return;
@@ -221,8 +224,8 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, g = lane >> 4;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= p.total_tiles) return;
+  const int tile = SPLIT ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  if (!SPLIT && tile >= p.total_tiles) return;
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < DTF_MAX_WGRAD_PROBLEMS; ++i)
@@ -255,7 +258,8 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
   }
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  for (int kb = 0; kb < q.Kb; kb += 16 * CH) {
+  // SPLIT: wave w takes the passes w, w + 4, ... (k >= Kb reads zeros, so a ragged last pass needs no care)
+  for (int kb = SPLIT ? wave * 16 * CH : 0; kb < q.Kb; kb += (SPLIT ? 4 : 1) * 16 * CH) {
     int xr[CH][4];
     float av[CH][4], bv[CH][4];
 #pragma unroll
@@ -282,6 +286,20 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(DtfWgradArgs p) {
       acc0 = MFMA16(av[i][2], bv[i][2], acc0);
       acc1 = MFMA16(av[i][3], bv[i][3], acc1);
     }
+  }
+  if constexpr (SPLIT) {
+    __shared__ float part[3][5][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave - 1][r][lane] = acc0[r] + acc1[r];
+      part[wave - 1][4][lane] = bsum;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc0[r] = ((acc0[r] + acc1[r]) + part[0][r][lane]) + (part[1][r][lane] + part[2][r][lane]);
+    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    bsum = (bsum + part[0][4][lane]) + (part[1][4][lane] + part[2][4][lane]);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -324,11 +342,10 @@ DTF_EXPORT int dtf_wgrad_grouped(const DtfWgradArgs* a, hipStream_t s) {
     if (a->tail.ridx_next && (a->tail.B <= 0 || a->tail.n_train <= 0 || a->tail.ridx_next == a->tail.ridx_cur)) return DTF_ERR_SHAPE;
     if (a->tail.nparts > 0 && (!a->tail.loss_part || !a->tail.correct_part || !a->tail.post_part)) return DTF_ERR_ARG;
   }
-  const int nblk = dtf_cdiv(tiles, 4) + 1;
   bool long_k = true;
   for (int i = 0; i < a->nprob; ++i) long_k = long_k && a->prob[i].Kb >= 1024;
-  if (long_k) hipLaunchKernelGGL(wgrad_grouped_kernel<16>, dim3(nblk), dim3(256), 0, s, *a);
-  else hipLaunchKernelGGL(wgrad_grouped_kernel<DTF_WGRAD_CH>, dim3(nblk), dim3(256), 0, s, *a);
+  if (long_k) hipLaunchKernelGGL((wgrad_grouped_kernel<16, true>), dim3(tiles + 1), dim3(256), 0, s, *a);
+  else hipLaunchKernelGGL((wgrad_grouped_kernel<DTF_WGRAD_CH, false>), dim3(dtf_cdiv(tiles, 4) + 1), dim3(256), 0, s, *a);
   return dtf_check_launch();
 }
 

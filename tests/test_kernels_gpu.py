@@ -74,7 +74,9 @@ def test_linear_bwd_data(M, K, N):
     _close(got, want)
 
 
-@pytest.mark.parametrize("B,D,H,C", [(100, 784, 100, 10), (128, 784, 4096, 10), (7, 20, 12, 3), (1, 784, 100, 10)])
+# batches of 1024 rows and more take the variant that deals the batch rows of one tile to the four waves
+@pytest.mark.parametrize("B,D,H,C", [(100, 784, 100, 10), (128, 784, 4096, 10), (7, 20, 12, 3), (1, 784, 100, 10),
+                                     (4096, 40, 512, 10), (1031, 33, 20, 7)])
 def test_wgrad_grouped_store(B, D, H, C):
     x, h = _rand(B, D, seed=1), _rand(B, H, seed=2)
     dz1, dz2p = _rand(B, H, seed=3), torch.zeros(B, 16)
@@ -92,8 +94,9 @@ def test_wgrad_grouped_store(B, D, H, C):
     _close(db2, b2)
 
 
-def test_wgrad_grouped_fused_sgd_and_rows():
-    B, D, H, N = 100, 784, 100, 1000
+@pytest.mark.parametrize("B,N", [(100, 1000), (1300, 2000)])
+def test_wgrad_grouped_fused_sgd_and_rows(B, N):
+    D, H = 784, 100
     data = _rand(N, D, seed=1)
     rows = torch.randperm(N, generator=torch.Generator().manual_seed(9))[:B].to(torch.int32)
     dz1 = _rand(B, H, seed=3)
