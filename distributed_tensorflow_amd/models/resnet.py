@@ -1,7 +1,8 @@
 """ResNet-50 on the sharded parameter-server state (BASELINE configuration 5).
 
 The convolutions are library calls (MIOpen through PyTorch): the reference has no convolutional
-model, and the hand-written hot path of this framework is the dense path.  What this model
+model, and the hand-written hot path of this framework is the dense path; batch normalisation, the
+residual additions and the ReLUs run in the fused kernels of ``ops/batchnorm.py``.  What this model
 exercises is the parameter-server side at a realistic size (25.6 M parameters, 161 tensors):
 all trainable tensors are views into ONE flat fp32 buffer, autograd writes gradients into the
 matching flat gradient buffer, and a step is
@@ -22,6 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..ops.batchnorm import FusedBatchNormAct
 from ..parallel.sharded_state import ShardedState, VariableSpec
 from .mlp import StepRecord
 
@@ -32,19 +34,18 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = FusedBatchNormAct(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = FusedBatchNormAct(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.bn3 = FusedBatchNormAct(planes * 4)
         self.downsample = downsample
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = F.relu(self.bn1(self.conv1(x)), inplace=True)
-        out = F.relu(self.bn2(self.conv2(out)), inplace=True)
-        out = self.bn3(self.conv3(out))
-        return F.relu(out + idt, inplace=True)
+        out = self.bn1(self.conv1(x))                    # batch norm + ReLU: one operator (ops/batchnorm.py)
+        out = self.bn2(self.conv2(out))
+        return self.bn3(self.conv3(out), residual=idt)   # batch norm + residual + ReLU
 
 
 class ResNet(nn.Module):
@@ -52,7 +53,7 @@ class ResNet(nn.Module):
         super().__init__()
         self.inplanes = width
         self.conv1 = nn.Conv2d(3, width, 7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(width)
+        self.bn1 = FusedBatchNormAct(width)
         self.layer1 = self._make(width, layers[0], 1)
         self.layer2 = self._make(width * 2, layers[1], 2)
         self.layer3 = self._make(width * 4, layers[2], 2)
@@ -66,14 +67,14 @@ class ResNet(nn.Module):
         down = None
         if stride != 1 or self.inplanes != planes * 4:
             down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
-                                 nn.BatchNorm2d(planes * 4))
+                                 FusedBatchNormAct(planes * 4, relu=False))
         layers = [Bottleneck(self.inplanes, planes, stride, down)]
         self.inplanes = planes * 4
         layers += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        x = self.bn1(self.conv1(x))
         x = F.max_pool2d(x, 3, stride=2, padding=1)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
