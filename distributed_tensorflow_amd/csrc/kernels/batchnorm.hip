@@ -61,7 +61,8 @@ __device__ __forceinline__ Walk make_walk(int C) {
 }
 
 // Sums two 8-channel vectors per thread over the threads of the block that own the same channels and stores
-// one partial per block: part[(2 * block + which) * C + c].
+// one partial per block: part[(which * C + c) * row_blocks + block] (a channel's partials are contiguous: the
+// finalize kernels read them with one wave per channel).
 __device__ __forceinline__ void block_column_sums(const float* s0, const float* s1, int C, float* __restrict__ part) {
   __shared__ float red[2][kBnThreads][9];      // 9: threads of one channel group are 1 row apart -> spread the banks
   const int cw = chunk_width(C), tpr = cw >> 3, rpi = kBnThreads / tpr;
@@ -74,7 +75,7 @@ __device__ __forceinline__ void block_column_sums(const float* s0, const float* 
     const int t0 = c >> 3, j = c & 7;
     float a = 0.f;
     for (int r = 0; r < rpi; ++r) a += red[which][t0 + r * tpr][j];
-    part[((size_t)2 * blockIdx.x + which) * C + (size_t)blockIdx.y * cw + c] = a;
+    part[((size_t)which * C + (size_t)blockIdx.y * cw + c) * gridDim.x + blockIdx.x] = a;
   }
 }
 
@@ -108,20 +109,16 @@ __global__ __launch_bounds__(kBnThreads) void bn_finalize_fwd_kernel(const float
                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                       float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                       float* __restrict__ save, float momentum, float eps) {
-  __shared__ double red[2][16][17];
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;    // one wave per channel
+  if (c >= C) return;
   double s = 0.0, ss = 0.0;
-  if (c < C)
-    for (int g = sl; g < nblk; g += 16) {
-      s += (double)part[((size_t)2 * g) * C + c];
-      ss += (double)part[((size_t)2 * g + 1) * C + c];
-    }
-  red[0][sl][cl] = s;
-  red[1][sl][cl] = ss;
-  __syncthreads();
-  if (sl == 0 && c < C) {
-    for (int i = 1; i < 16; ++i) { s += red[0][i][cl]; ss += red[1][i][cl]; }
+  for (int g = lane; g < nblk; g += 64) {
+    s += (double)part[(size_t)c * nblk + g];
+    ss += (double)part[((size_t)C + c) * nblk + g];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+  if (lane == 0) {
     const double mean = s / (double)M;
     double var = ss / (double)M - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -229,20 +226,16 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const unsigne
 __global__ __launch_bounds__(kBnThreads) void bn_finalize_bwd_kernel(const float* __restrict__ part, int nblk, int64_t M, int C,
                                                                       const float* __restrict__ save, float* __restrict__ dgamma,
                                                                       float* __restrict__ dbeta, float* __restrict__ coef) {
-  __shared__ double red[2][16][17];
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;    // one wave per channel
+  if (c >= C) return;
   double s = 0.0, sx = 0.0;
-  if (c < C)
-    for (int g = sl; g < nblk; g += 16) {
-      s += (double)part[((size_t)2 * g) * C + c];
-      sx += (double)part[((size_t)2 * g + 1) * C + c];
-    }
-  red[0][sl][cl] = s;
-  red[1][sl][cl] = sx;
-  __syncthreads();
-  if (sl == 0 && c < C) {
-    for (int i = 1; i < 16; ++i) { s += red[0][i][cl]; sx += red[1][i][cl]; }
+  for (int g = lane; g < nblk; g += 64) {
+    s += (double)part[(size_t)c * nblk + g];
+    sx += (double)part[((size_t)C + c) * nblk + g];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); sx += __shfl_xor(sx, o); }
+  if (lane == 0) {
     const double rstd = (double)save[C + c], a = (double)save[2 * C + c];
     dgamma[c] = (float)(sx * rstd);
     dbeta[c] = (float)s;
@@ -328,7 +321,7 @@ DTF_EXPORT int dtf_bn_fwd(const void* x, const void* res, void* y, const float* 
   const auto* rs = static_cast<const unsigned short*>(res);
   auto* ys = static_cast<unsigned short*>(y);
   hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, s, xs, M, C, part);
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(dtf_cdiv(C, 16)), dim3(kBnThreads), 0, s, part, nblk, M, C, gamma, beta, running_mean,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(dtf_cdiv(C, 4)), dim3(kBnThreads), 0, s, part, nblk, M, C, gamma, beta, running_mean,
                      running_var, save, momentum, eps);
   if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(kBnThreads), 0, s, xs, rs, ys, save, M, C);
   else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(kBnThreads), 0, s, xs, rs, ys, save, M, C);
@@ -356,7 +349,7 @@ DTF_EXPORT int dtf_bn_bwd(const void* dy, const void* x, const void* y, void* dx
   if (mask == 2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, grid, dim3(kBnThreads), 0, s, ds, xs, ys, drs, save, M, C, part);
   else if (mask == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(kBnThreads), 0, s, ds, xs, ys, drs, save, M, C, part);
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, dim3(kBnThreads), 0, s, ds, xs, ys, drs, save, M, C, part);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(dtf_cdiv(C, 16)), dim3(kBnThreads), 0, s, part, nblk, M, C, save, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(dtf_cdiv(C, 4)), dim3(kBnThreads), 0, s, part, nblk, M, C, save, dgamma, dbeta, coef);
   if (mask == 2) hipLaunchKernelGGL(bn_bwd_dx_kernel<0>, grid, dim3(kBnThreads), 0, s, drs, xs, dxs, save, coef, M, C);
   else if (mask == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<1>, grid, dim3(kBnThreads), 0, s, ds, xs, dxs, save, coef, M, C);
   else hipLaunchKernelGGL(bn_bwd_dx_kernel<0>, grid, dim3(kBnThreads), 0, s, ds, xs, dxs, save, coef, M, C);
