@@ -144,6 +144,7 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
 
 def bench_resnet50_sync(args, rank, world, device):
     from .models.resnet import TorchModuleProgram, resnet50
+    from .ops.batchnorm import calls as bn_calls
     batch = args.batch_size or 256
     optimizer = args.optimizer or "adam"
     dtype_name = args.dtype or "bf16"
@@ -177,7 +178,9 @@ def bench_resnet50_sync(args, rank, world, device):
         "config": {"model": "ResNet-50", "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
                    "parallelism": f"dp{world} sync_replicas, optimizer state sharded over {world} GPU(s)",
                    "optimizer": optimizer, "mode": "sync", "collective": engine.collective if world > 1 else "none",
-                   "params": prog.state.layout.used, "convolutions": "MIOpen (library)"},
+                   "params": prog.state.layout.used, "convolutions": "MIOpen (library)",
+                   "batch_norm": ("fused kernels (batchnorm.hip)" if bn_calls["kernel"] and not bn_calls["operators"]
+                                  else "PyTorch operators" if not bn_calls["kernel"] else "mixed")},
         "final_loss": last.loss,
     }
 

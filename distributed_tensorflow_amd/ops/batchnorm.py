@@ -27,6 +27,7 @@ from . import _lib
 
 _workspaces = {}
 _protos_done = False
+calls = {"kernel": 0, "operators": 0}     # forward calls by path (benchmarks report which one ran)
 
 
 def _kernels():
@@ -127,7 +128,9 @@ class _BnAct(torch.autograd.Function):
 def bn_act(x, weight, bias, running_mean=None, running_var=None, residual=None, relu=True, training=True,
            momentum=0.1, eps=1e-5):
     """``act(batch_norm(x) [+ residual])`` with the batch statistics of ``x`` (training) or the running ones."""
-    if kernel_path_takes(x, residual, training):
+    takes = kernel_path_takes(x, residual, training)
+    calls["kernel" if takes else "operators"] += 1
+    if takes:
         return _BnAct.apply(x, weight, bias, running_mean, running_var, residual, relu, momentum, eps)
     return reference_bn_act(x, weight, bias, running_mean, running_var, residual, relu, training, momentum, eps)
 
