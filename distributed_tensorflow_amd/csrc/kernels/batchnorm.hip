@@ -3,8 +3,8 @@
 //
 //     y = act(gamma * (x - mean) * rstd + beta [+ residual])            x, y, residual: [M, C] bf16, M = N*H*W
 //
-// The library sequence (batch norm, add, ReLU as three operators) moves every activation 13 times per training
-// step; here it moves 7 times:
+// As three operators (batch norm, add, ReLU) a layer costs 13 tensor-sized memory passes per training step without
+// a residual and 16 with one; here 8 and 11:
 //   forward   stats (read x) -> finalize ([C]) -> normalize (read x [, residual], write y)
 //   backward  reduce (read dy, x [, y]; write the masked dy when a residual branch needs it) -> finalize ([C])
 //             -> dx (read dy, x; write dx)
