@@ -1,4 +1,5 @@
-"""ResNet-50 on the sharded parameter-server state (BASELINE configuration 5).
+"""ResNet-50 on the sharded parameter-server state (benchmark configuration "resnet50_sync": synthetic
+ImageNet-shape data, sync mode, optimizer state sharded over the ranks).
 
 The convolutions are library calls (MIOpen through PyTorch): the reference has no convolutional
 model, and the hand-written hot path of this framework is the dense path; batch normalisation, the

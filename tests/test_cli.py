@@ -59,7 +59,7 @@ def test_missing_job_name_is_a_value_error():
 
 @pytest.mark.slow
 def test_one_ps_two_workers_sync_matches_single_process_big_batch():
-    """BASELINE configuration 1: 1 ps + 2 workers on CPU, sync mode.  The mean of the two workers'
+    """The CPU correctness configuration: 1 ps + 2 workers on CPU, sync mode.  The mean of the two workers'
     gradients applied once equals one step on the union batch, so every worker sees the same
     global steps and the run converges like a batch-200 run."""
     port_w0, port_w1, port_ps = free_port(), free_port(), free_port()
