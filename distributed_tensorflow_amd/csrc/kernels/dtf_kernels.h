@@ -90,6 +90,9 @@ struct DtfHeadArgs {
   float inv_b;
   unsigned h_bytes;         // bytes addressable from Hact
   int pad_;
+  void* dz1_bf;             // optional: dz1 as bf16 [M_train, Hd] (ld_bf) ...
+  void* dz1_bf_t;           // ... and transposed [Hd, >= M_train] (ld_bf_t, a multiple of 4): the operands of the next
+  int ld_bf, ld_bf_t;       //     bf16 products, written here instead of by a cast pass over the fp32 dz1 (which may be null)
 };
 
 // Two-launch training step of the one-hidden-layer network (mlp2_fused.hip): launch 1 = hidden layer

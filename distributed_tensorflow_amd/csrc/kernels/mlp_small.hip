@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
   const int C = p.C, Hd = p.Hd;
   const float NEG_INF = -__builtin_huge_valf();
   const bool cls_ok = fr < C;
-  const bool train_tile = r0 < p.M_train && p.dz1 != nullptr;   // workgroup-uniform
+  const bool train_tile = r0 < p.M_train && (p.dz1 != nullptr || p.dz1_bf != nullptr);   // workgroup-uniform
   const int nchunk = (Hd + 15) >> 4;
   const rsrc_t rh = make_rsrc(p.Hact, p.h_bytes), rw = make_rsrc(p.W2, (unsigned)Hd * (unsigned)C * 4u);
 
@@ -508,11 +508,37 @@ __global__ __launch_bounds__(256) void head_kernel(DtfHeadArgs p) {
       d1 = MFMA16(a4[1], cw[i][1], d1);
       d0 = MFMA16(a4[2], cw[i][2], d0);
       d1 = MFMA16(a4[3], cw[i][3], d1);
+      float dv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int orow = r0 + 4 * g + r;
-        if (orow < p.M_train && hcol < Hd)
-          p.dz1[(size_t)orow * p.ld_dz1 + hcol] = cact[i][r] > 0.f ? d0[r] + d1[r] : 0.f;
+        dv[r] = cact[i][r] > 0.f ? d0[r] + d1[r] : 0.f;
+        if (p.dz1 && orow < p.M_train && hcol < Hd) p.dz1[(size_t)orow * p.ld_dz1 + hcol] = dv[r];
+      }
+      if (p.dz1_bf && hcol < Hd) {
+        // compute-dtype copies for the bf16 products below: row-major (2 bytes per lane, 32 contiguous bytes per
+        // 16 lanes) and transposed (this lane's 4 rows are 8 contiguous bytes)
+        unsigned short* bf = static_cast<unsigned short*>(p.dz1_bf);
+        unsigned short* bft = static_cast<unsigned short*>(p.dz1_bf_t);
+        unsigned short hb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hb[r] = __builtin_bit_cast(unsigned short, (__bf16)dv[r]);
+          if (r0 + 4 * g + r < p.M_train) bf[(size_t)(r0 + 4 * g + r) * p.ld_bf + hcol] = hb[r];
+        }
+        if (bft) {
+          const size_t e = (size_t)hcol * p.ld_bf_t + r0 + 4 * g;
+          if (r0 + 4 * g + 3 < p.M_train) {
+            uint2 q;
+            q.x = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
+            q.y = (unsigned)hb[2] | ((unsigned)hb[3] << 16);
+            *reinterpret_cast<uint2*>(bft + e) = q;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (r0 + 4 * g + r < p.M_train) bft[e + r] = hb[r];
+          }
+        }
       }
     }
   }
@@ -523,6 +549,10 @@ DTF_EXPORT int dtf_head(const DtfHeadArgs* a, hipStream_t s) {
   if (a->M_total <= 0 || a->M_train < 0 || a->M_train > a->M_total) return DTF_ERR_SHAPE;
   if (a->C <= 0 || a->C > 16 || a->Hd <= 0 || a->ldh < a->Hd) return DTF_ERR_SHAPE;
   if (a->M_train > 0 && a->dz1 && a->ld_dz1 < a->Hd) return DTF_ERR_SHAPE;
+  if (a->dz1_bf_t && !a->dz1_bf) return DTF_ERR_ARG;
+  if (a->M_train > 0 && a->dz1_bf && a->ld_bf < a->Hd) return DTF_ERR_SHAPE;
+  if (a->M_train > 0 && a->dz1_bf_t && (a->ld_bf_t < a->M_train || (a->ld_bf_t & 3) || (reinterpret_cast<uintptr_t>(a->dz1_bf_t) & 7u)))
+    return DTF_ERR_ALIGN;
   if (((a->ldh | a->Hd) & 3) == 0 && !dtf_aligned16(a->Hact)) return DTF_ERR_ALIGN;
   if (a->h_bytes == 0 || a->h_bytes >= kOOB || ((uint64_t)(a->M_total - 1) * a->ldh + a->Hd) * 4u > a->h_bytes) return DTF_ERR_SHAPE;
   if ((uint64_t)a->Hd * a->C * 4u >= kOOB) return DTF_ERR_SHAPE;

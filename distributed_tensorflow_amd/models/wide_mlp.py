@@ -57,15 +57,28 @@ class WideMLPProgram(MLPProgram):
         self.grad_ready = None              # engine hook: called with a bucket index of grad_groups()
         self.folded = [False] * len(hidden)  # layers whose weight-gradient epilogue applies the optimizer itself
         del self.schedule_tail_entries      # this program enqueues op by op; the engine then uses after_compute
+        if self.is_cuda:
+            self._args = [self._build_args(q) for q in range(self.P)]      # now with the compute-dtype buffers
 
     def grad_groups(self):
         """Gradient buckets in layout order: one per hidden layer, then the output layer."""
         return [[f"{n}_w", f"{n}_b"] for n in self.names] + [["sm_w", "sm_b"]]
 
+    def _head_dz(self):
+        """Where the head writes dz of the last hidden layer: with bf16 products straight into their operands (row-major
+        and transposed copy), else as fp32 for the cast that follows."""
+        if self._head_writes_bf16():
+            return {"dz1": None, "dz1_bf": self.dzc[-1], "dz1_bf_t": self.dzc_t[-1]}
+        return {"dz1": self.dz[-1]}
+
+    def _head_writes_bf16(self) -> bool:
+        # (the base constructor builds its arguments before the compute-dtype buffers exist; they are rebuilt below)
+        return self.cdtype == torch.bfloat16 and hasattr(self, "dzc_t") and self.dzc_t[-1].stride(0) % 4 == 0
+
     def _build_args(self, q: int):
         st = self.state
         head = ops.build_head_args(self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B,
-                                   self.loss_mode, rows=self.ridx[q], dz2=self.dz2, dz1=self.dz[-1],
+                                   self.loss_mode, rows=self.ridx[q], dz2=self.dz2, **self._head_dz(),
                                    loss_part=self.loss_part, correct_part=self.correct_part, post_part=self.post_part)
         items = [ops.WgradItem(self.hact[-1], self.dz2, self.B, n=self.C, dw=st.grad("sm_w"), db=st.grad("sm_b"),
                                w=st.var("sm_w"), b=st.var("sm_b"))]
@@ -140,10 +153,11 @@ class WideMLPProgram(MLPProgram):
             ops.head(self.hl32, st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, B, args=self._args[q]["head"])
         else:
             ops.head(self.hl32, st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, B, self.loss_mode, rows=rows,
-                     dz2=self.dz2, dz1=self.dz[-1], loss_part=self.loss_part, correct_part=self.correct_part,
-                     post_part=self.post_part)
-        # dz of the last hidden layer: fp32 from the head -> compute dtype + transposed copy
-        ops.gather_cast_transpose(self.dz[-1], None, self.dzc[-1], self.dzc_t[-1], m=B)
+                     dz2=self.dz2, loss_part=self.loss_part, correct_part=self.correct_part,
+                     post_part=self.post_part, **self._head_dz())
+        if not self._head_writes_bf16():
+            # dz of the last hidden layer: fp32 from the head -> compute dtype + transposed copy
+            ops.gather_cast_transpose(self.dz[-1], None, self.dzc[-1], self.dzc_t[-1], m=B)
         # fp32 runs read the master weights in the backward product, which the bucket's all-gather rewrites:
         # there the bucket is released only after that product has been enqueued
         early = self.grad_ready is not None and self.w[0] is not None

@@ -203,7 +203,7 @@ def wgrad_grouped(items, lr=None, tail=None, args=None):
 
 # --------------------------------------------------------------------------- head
 def build_head_args(hact, w2, b2, labels, m_total, m_train, loss_mode, rows=None, dz2=None, dz1=None, probs=None,
-                    loss_part=None, correct_part=None, post_part=None):
+                    loss_part=None, correct_part=None, post_part=None, dz1_bf=None, dz1_bf_t=None):
     hd, c = w2.shape
     if c > 16:
         raise ValueError("head: at most 16 classes")
@@ -226,6 +226,12 @@ def build_head_args(hact, w2, b2, labels, m_total, m_train, loss_mode, rows=None
             raise ValueError("head: dz1 shape mismatch")
     if probs is not None and (probs.shape[0] < m_total or probs.shape[1] != c or not probs.is_contiguous()):
         raise ValueError("head: probs shape mismatch")
+    if dz1_bf is not None and (dz1_bf.dtype != torch.bfloat16 or dz1_bf.shape[0] < m_train or dz1_bf.shape[1] != hd
+                               or dz1_bf.stride(1) != 1):
+        raise ValueError("head: dz1_bf must be bf16 [>=m_train, hidden], row-major")
+    if dz1_bf_t is not None and (dz1_bf is None or dz1_bf_t.dtype != torch.bfloat16 or dz1_bf_t.shape[0] != hd
+                                 or dz1_bf_t.shape[1] < m_train or dz1_bf_t.stride(1) != 1):
+        raise ValueError("head: dz1_bf_t must be bf16 [hidden, >=m_train], row-major, next to dz1_bf")
     return _lib.HeadArgs(Hact=_f32c(hact, "hact").data_ptr(), W2=_f32c(w2, "w2").data_ptr(), b2=_f32c(b2, "b2").data_ptr(),
                          labels=_f32c(labels, "labels").data_ptr(),
                          rows=_lib.ptr(None if rows is None else _i32c(rows, "rows")), dz2=_lib.ptr(dz2),
@@ -233,15 +239,17 @@ def build_head_args(hact, w2, b2, labels, m_total, m_train, loss_mode, rows=None
                          correct_part=_lib.ptr(correct_part), post_part=_lib.ptr(post_part), M_total=m_total,
                          M_train=m_train, Hd=hd, C=c, ldh=hact.stride(0), ld_dz1=0 if dz1 is None else dz1.stride(0),
                          loss_mode=loss_mode, inv_b=(1.0 / m_train) if m_train else 0.0,
-                         h_bytes=_lib.span_bytes(hact), pad_=0)
+                         h_bytes=_lib.span_bytes(hact), pad_=0, dz1_bf=_lib.ptr(dz1_bf), dz1_bf_t=_lib.ptr(dz1_bf_t),
+                         ld_bf=0 if dz1_bf is None else dz1_bf.stride(0), ld_bf_t=0 if dz1_bf_t is None else dz1_bf_t.stride(0))
 
 
 def head(hact, w2, b2, labels, m_total, m_train, loss_mode=LOSS_REFERENCE, rows=None, dz2=None, dz1=None, probs=None,
-         loss_part=None, correct_part=None, post_part=None, args=None):
+         loss_part=None, correct_part=None, post_part=None, args=None, dz1_bf=None, dz1_bf_t=None):
     """Fused last layer: logits, softmax, (double-)softmax cross-entropy, accuracy counts,
     dz2 and dz1 (K2-K5 + K7 of the reference graph, distributed.py:81-87)."""
     if not hact.is_cuda:
-        r = reference.head(hact[:m_total], w2, b2, labels, m_train, loss_mode, rows, want_dz1=dz1 is not None)
+        r = reference.head(hact[:m_total], w2, b2, labels, m_train, loss_mode, rows,
+                           want_dz1=dz1 is not None or dz1_bf is not None)
         if probs is not None:
             probs[:m_total].copy_(r["probs"])
         if m_train > 0:
@@ -250,6 +258,10 @@ def head(hact, w2, b2, labels, m_total, m_train, loss_mode=LOSS_REFERENCE, rows=
                 dz2[:m_train, :w2.shape[1]].copy_(r["dz2"])
             if dz1 is not None:
                 dz1[:m_train].copy_(r["dz1"])
+            if dz1_bf is not None:
+                dz1_bf[:m_train].copy_(r["dz1"])
+                if dz1_bf_t is not None:
+                    dz1_bf_t[:, :m_train].copy_(dz1_bf[:m_train].t())
         for t, v in ((loss_part, r["loss_sum"]), (correct_part, r["correct"]), (post_part, r["post_correct"])):
             if t is not None:
                 t.zero_()
@@ -257,7 +269,7 @@ def head(hact, w2, b2, labels, m_total, m_train, loss_mode=LOSS_REFERENCE, rows=
         return r
     if args is None:
         args = build_head_args(hact, w2, b2, labels, m_total, m_train, loss_mode, rows, dz2, dz1, probs, loss_part,
-                               correct_part, post_part)
+                               correct_part, post_part, dz1_bf, dz1_bf_t)
     _lib.check(_lib.kernels().dtf_head(C.byref(args), _lib.stream_handle()), "head")
     return args
 

@@ -61,7 +61,8 @@ class HeadArgs(C.Structure):
                 ("dz2", C.c_void_p), ("dz1", C.c_void_p), ("probs", C.c_void_p), ("loss_part", C.c_void_p),
                 ("correct_part", C.c_void_p), ("post_part", C.c_void_p), ("M_total", C.c_int), ("M_train", C.c_int),
                 ("Hd", C.c_int), ("C", C.c_int), ("ldh", C.c_int), ("ld_dz1", C.c_int), ("loss_mode", C.c_int),
-                ("inv_b", C.c_float), ("h_bytes", C.c_uint), ("pad_", C.c_int)]
+                ("inv_b", C.c_float), ("h_bytes", C.c_uint), ("pad_", C.c_int), ("dz1_bf", C.c_void_p),
+                ("dz1_bf_t", C.c_void_p), ("ld_bf", C.c_int), ("ld_bf_t", C.c_int)]
 
 
 class GemmArgs(C.Structure):

@@ -235,3 +235,23 @@ def test_optimizer_over_ranges_matches_the_flat_kernels(adam):
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert torch.equal(a[0][1024:4096].cpu(), p0[1024:4096])
+
+
+def test_head_writes_bf16_operands_of_the_next_products():
+    """dz1 straight into the bf16 operands (row-major + transposed) instead of fp32 + a cast pass."""
+    M, H, C = 200, 1024, 10
+    hact = torch.relu(_rand(M, H, seed=1)).to(DEV)
+    w2, b2 = _rand(H, C, seed=2, scale=0.3).to(DEV), _rand(C, seed=3, scale=0.1).to(DEV)
+    lab = torch.nn.functional.one_hot(torch.randint(0, C, (M,), generator=torch.Generator().manual_seed(4)), C).float().to(DEV)
+    dz2a, dz2b = torch.zeros(M, 16, device=DEV), torch.zeros(M, 16, device=DEV)
+    dz1 = torch.zeros(M, H, device=DEV)
+    ops.head(hact, w2, b2, lab, M, M, dz2=dz2a, dz1=dz1)
+    bf = torch.zeros(M, H, dtype=torch.bfloat16, device=DEV)
+    bft = torch.zeros(H, 208, dtype=torch.bfloat16, device=DEV)       # leading dimension a multiple of 4, > M
+    ops.head(hact, w2, b2, lab, M, M, dz2=dz2b, dz1_bf=bf, dz1_bf_t=bft)
+    assert torch.equal(dz2a, dz2b)
+    assert torch.equal(bf, dz1.bfloat16())
+    assert torch.equal(bft[:, :M], dz1.bfloat16().t())
+    assert float(bft[:, M:].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops.head(hact, w2, b2, lab, M, M, dz2=dz2b, dz1_bf=bf, dz1_bf_t=torch.zeros(H, 202, dtype=torch.bfloat16, device=DEV))
