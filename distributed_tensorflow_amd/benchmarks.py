@@ -270,6 +270,5 @@ def run_benchmark(args):
         res = bench_mlp_async(args, rank, world, device, wide=True)
     else:
         raise SystemExit(f"config {args.config} is not wired into bench.py yet")
-    if world > 1:
-        comm.shutdown()
+    comm.shutdown()                 # also the one-rank group some configurations create
     return res if rank == 0 else None
