@@ -313,6 +313,38 @@ class MLPProgram:
             self._graphs[key] = g
         return g
 
+    def _launch_sizes(self, n_steps: int, graph_steps: int):
+        """Steps per launch of a run of ``n_steps``: whole graphs of ``graph_steps``, then powers of two, then single
+        steps."""
+        limit = self.data.max_steps_per_launch(self.B)
+        graph_steps = max(2, min(graph_steps, limit) & ~1)
+        remaining = n_steps
+        while remaining > 0:
+            if self.use_graphs and remaining >= 2:
+                n = graph_steps if remaining >= graph_steps else 1 << (remaining.bit_length() - 1)
+                n = min(n, graph_steps)
+            else:
+                n = 1
+            yield n
+            remaining -= n
+
+    def prepare_graphs(self, n_steps: int, graph_steps: int = 64) -> None:
+        """Capture and instantiate, without launching anything, the hipGraphs the next ``run(n_steps, graph_steps)``
+        will replay (a graph is keyed by its length and the buffer slot it starts on): set-up cost kept out of a
+        timed run."""
+        if not self.use_graphs:
+            return
+        if not self._started:
+            self.start()
+        saved = self.steps_enqueued
+        try:
+            for n in self._launch_sizes(n_steps, graph_steps):
+                if n >= 2:
+                    self._graph_for(n)
+                self.steps_enqueued += n
+        finally:
+            self.steps_enqueued = saved
+
     def run(self, n_steps: int, graph_steps: int = 64) -> None:
         """Enqueue ``n_steps`` steps; returns without waiting for the device."""
         if not self._started:
