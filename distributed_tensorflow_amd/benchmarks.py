@@ -247,6 +247,8 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
         finish = engine.finish
     _sync_all(device, world)
     engine.run(args.warmup, 64)
+    if type(engine).__name__ in ("PeerMappedAsyncEngine", "SyncReplicasEngine"):    # engines whose steps replay from graphs
+        _prepare_graphs(prog, args, 64, device)
     _sync_all(device, world)
     t0 = time.perf_counter()
     engine.run(args.steps, 64)
