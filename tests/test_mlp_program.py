@@ -89,6 +89,27 @@ def test_deep_mlp_cpu_matches_autograd():
 
 
 @pytest.mark.gpu
+def test_gpu_prepared_graphs_are_the_ones_the_run_replays():
+    """prepare_graphs captures, without launching, exactly the graphs the next run needs: the run creates none and
+    the trajectory is the one of a program that captured on the fly."""
+    _, st_a, prog_a, _ = _make("cuda", lr=0.3, use_graphs=True)
+    _, st_b, prog_b, _ = _make("cuda", lr=0.3, use_graphs=True)
+    for prog in (prog_a, prog_b):
+        prog.run(7, graph_steps=4)
+    before = prog_a.state.global_step()
+    prog_a.prepare_graphs(23, graph_steps=8)
+    torch.cuda.synchronize()
+    assert prog_a.state.global_step() == before and prog_a.steps_enqueued == 7       # nothing ran
+    n_graphs = len(prog_a._graphs)
+    prog_a.run(23, graph_steps=8)
+    prog_b.run(23, graph_steps=8)
+    assert len(prog_a._graphs) == n_graphs == len(prog_b._graphs)
+    ra, rb = prog_a.read_log(0, 30), prog_b.read_log(0, 30)
+    assert [r.loss for r in ra] == [r.loss for r in rb]
+    assert torch.equal(st_a.params, st_b.params) and st_a.global_step() == 31
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hidden,post,graphs", [((100,), True, True), ((100,), False, False), ((64, 48), True, True)])
 def test_gpu_trajectory_matches_cpu(hidden, post, graphs):
     steps = 37
