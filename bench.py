@@ -4,8 +4,14 @@
 trained synchronously with the parameter-server state sharded across the GPUs.
 
     python bench.py --gpus 1 --steps 2000 --warmup 200
+    python bench.py --gpus 8 --steps 2000 --warmup 200          # starts its own 8 worker processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W  # the same under an external launcher
+
+This mirrors the reference's launch recipe (one process per worker GPU, /root/reference/README.md:7-15):
+with ``--gpus N`` and no ``WORLD_SIZE`` in the environment this process never touches a GPU; it starts N
+fresh worker processes (``LOCAL_RANK`` = GPU index, a free rendezvous port on 127.0.0.1), forwards their
+stderr, prints rank 0's ONE JSON line and exits non-zero if any worker does.
 
 Every step does the full reference iteration: forward, (double-softmax) loss,
 accuracy, backward, gradient aggregation over the workers, SGD update of the
@@ -19,17 +25,18 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -42,16 +49,92 @@ def parse_args():
     ap.add_argument("--dtype", default=None)
     ap.add_argument("--no_post_update_accuracy", action="store_true")
     ap.add_argument("--graph_steps", type=int, default=0)
-    ap.add_argument("--collective", default="auto", choices=["auto", "reduce_scatter", "all_reduce", "bucketed"])
+    ap.add_argument("--collective", default="auto",
+                    choices=["auto", "reduce_scatter", "all_reduce", "bucketed", "p2p_sharded", "p2p_replicated"])
+    ap.add_argument("--staleness", type=int, default=None, help="async configs: pull every (staleness+1)-th step")
+    ap.add_argument("--replicas_to_aggregate", type=int, default=None, help="sync configs: R (default: the number of workers)")
+    ap.add_argument("--no_second_mode", action="store_true",
+                    help="N>1, mlp_sync: skip the extra timed segment in the other update mode (async_value)")
     ap.add_argument("--cpu", action="store_true", help="run on CPU with gloo (functional check only)")
     ap.add_argument("--force_collectives", action="store_true",
                     help="N=1 only: run the multi-rank code path (gradient store, RCCL collective on a one-rank "
                          "communicator, separate optimizer launch) to measure its overhead without peers")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse_args()
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _pump(stream, sink, prefix: str) -> None:
+    for line in iter(stream.readline, ""):
+        sink.write(prefix + line)
+        sink.flush()
+    stream.close()
+
+
+def launch_workers(args, argv) -> int:
+    """Start one worker process per GPU and relay rank 0's JSON line.  The parent makes no HIP call: the
+    children are fresh interpreters created before anything here could have initialised a GPU."""
+    n = args.gpus
+    env_base = dict(os.environ)
+    env_base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL and the peer-mapped buffers need it
+    env_base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    if not args.cpu:
+        import torch                                              # device_count() does not initialise the GPU
+        have = torch.cuda.device_count()
+        if have == 0:
+            sys.stderr.write("[bench] no GPU visible: add --cpu for the gloo rehearsal\n")
+            return 2
+        if have < n and env_base.get("DTF_SHARE_GPU") != "1":
+            sys.stderr.write(f"[bench] --gpus {n} but {have} GPU(s) visible (DTF_SHARE_GPU=1 rehearses N ranks on fewer)\n")
+            return 2
+    procs, pumps = [], []
+    cmd = [sys.executable, "-u", os.path.abspath(__file__)] + list(argv)
+    for r in range(n):
+        env = dict(env_base, RANK=str(r), LOCAL_RANK=str(r), DTF_BENCH_CHILD="1")
+        p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, bufsize=1)
+        procs.append(p)
+        t = threading.Thread(target=_pump, args=(p.stderr, sys.stderr, f"[rank {r}] " if n > 1 else ""), daemon=True)
+        t.start()
+        pumps.append(t)
+    out0 = []
+    t0 = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    t0.start()
+    for r in range(1, n):       # other ranks print nothing on stdout; whatever appears goes to stderr
+        t = threading.Thread(target=_pump, args=(procs[r].stdout, sys.stderr, f"[rank {r} stdout] "), daemon=True)
+        t.start()
+        pumps.append(t)
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                sys.stderr.write(f"[bench] rank {r} exited with {code}; stopping the other workers\n")
+                for o in pending:
+                    procs[o].terminate()                          # exactly the processes started above
+        time.sleep(0.05)
+    t0.join(timeout=10)
+    for t in pumps:
+        t.join(timeout=5)
+    lines = [l for l in out0 if l.lstrip().startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write(f"[bench] expected one JSON line from rank 0, got {len(lines)}\n")
+        rc = 3
+    if rc == 0:
+        sys.stdout.write(lines[0] if lines[0].endswith("\n") else lines[0] + "\n")
+        sys.stdout.flush()
+    return rc
+
+
+def worker_main(args) -> None:
     # Libraries (RCCL prints a version banner at communicator creation) must not write to the stream
     # that carries the result: everything except the final JSON line goes to stderr.
     sys.stdout.flush()
@@ -59,7 +142,6 @@ def main():
     os.dup2(2, 1)
     # a long warm-up (library autotuning, first-touch compilation) must not look like a hang: one progress line
     # on stderr every 30 s
-    import threading
     t_start, done = time.time(), threading.Event()
 
     def heartbeat():
@@ -80,5 +162,17 @@ def main():
         print(json.dumps(result), flush=True)
 
 
+def main(argv=None) -> int:
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        sys.stderr.write("[bench] --gpus must be >= 1\n")
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_workers(args, argv)
+    worker_main(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

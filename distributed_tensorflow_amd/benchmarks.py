@@ -274,7 +274,7 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
 def run_benchmark(args):
     rank, world, device = _setup_distributed(args)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's process count and --gpus must agree")
     if args.config == "mlp_sync":
         res = bench_mlp_sync(args, rank, world, device, wide=False)
     elif args.config == "wide_mlp_sync":

@@ -313,32 +313,39 @@ class MLPProgram:
             self._graphs[key] = g
         return g
 
-    def _launch_sizes(self, n_steps: int, graph_steps: int):
-        """Steps per launch of a run of ``n_steps``: whole graphs of ``graph_steps``, then powers of two, then single
-        steps."""
+    def _launch_sizes(self, n_steps: int, graph_steps: int, exact_tail: bool = False):
+        """Steps per launch of a run of ``n_steps`` that starts at ``steps_enqueued``: whole graphs of ``graph_steps``,
+        then the rest.  The rest is ONE graph of exactly that many steps when such a graph exists already (or
+        ``exact_tail`` asks for it: ``prepare_graphs``), so that a prepared run of 20 steps is one replay; otherwise
+        powers of two, which bounds the number of different graphs an unprepared caller can make us capture."""
         limit = self.data.max_steps_per_launch(self.B)
         graph_steps = max(2, min(graph_steps, limit) & ~1)
-        remaining = n_steps
+        remaining, at = n_steps, self.steps_enqueued
         while remaining > 0:
             if self.use_graphs and remaining >= 2:
-                n = graph_steps if remaining >= graph_steps else 1 << (remaining.bit_length() - 1)
-                n = min(n, graph_steps)
+                if remaining >= graph_steps:
+                    n = graph_steps
+                elif exact_tail or (remaining, at % self.P) in self._graphs:
+                    n = remaining
+                else:
+                    n = 1 << (remaining.bit_length() - 1)
             else:
                 n = 1
             yield n
             remaining -= n
+            at += n
 
     def prepare_graphs(self, n_steps: int, graph_steps: int = 64) -> None:
         """Capture and instantiate, without launching anything, the hipGraphs the next ``run(n_steps, graph_steps)``
         will replay (a graph is keyed by its length and the buffer slot it starts on): set-up cost kept out of a
-        timed run."""
+        timed run.  The steps beyond the last whole graph become one graph of exactly that length."""
         if not self.use_graphs:
             return
         if not self._started:
             self.start()
         saved = self.steps_enqueued
         try:
-            for n in self._launch_sizes(n_steps, graph_steps):
+            for n in list(self._launch_sizes(n_steps, graph_steps, exact_tail=True)):
                 if n >= 2:
                     self._graph_for(n)
                 self.steps_enqueued += n
@@ -349,21 +356,13 @@ class MLPProgram:
         """Enqueue ``n_steps`` steps; returns without waiting for the device."""
         if not self._started:
             self.start()
-        limit = self.data.max_steps_per_launch(self.B)
-        graph_steps = max(2, min(graph_steps, limit) & ~1)
-        remaining = n_steps
-        while remaining > 0:
-            if self.use_graphs and remaining >= 2:
-                n = graph_steps if remaining >= graph_steps else 1 << (remaining.bit_length() - 1)
-                n = min(n, graph_steps)
-                self.data.prepare(self.steps_enqueued, n, self.B)
+        for n in list(self._launch_sizes(n_steps, graph_steps)):
+            self.data.prepare(self.steps_enqueued, n, self.B)
+            if n >= 2:
                 self._graph_for(n).replay()
                 self.steps_enqueued += n
             else:
-                n = 1
-                self.data.prepare(self.steps_enqueued, 1, self.B)
                 self.enqueue_step()
-            remaining -= n
 
     def read_log(self, first_local_step: int, count: int) -> List[StepRecord]:
         """Records of local steps ``[first, first+count)`` (0-based).  Synchronises with the device."""

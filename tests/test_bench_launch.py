@@ -1,0 +1,61 @@
+"""``python bench.py --gpus N`` with no launcher around it: the script starts its own N worker processes
+(one per GPU, like the reference's launch recipe /root/reference/README.md:7-15), prints rank 0's ONE JSON
+line and fails when a worker fails."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=ROOT)
+    return r
+
+
+def _one_json_line(r):
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                          # nothing but the result on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.slow
+def test_bench_starts_its_own_two_cpu_workers():
+    d = _one_json_line(_bench(["--gpus", "2", "--cpu", "--steps", "6", "--warmup", "2"]))
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0
+    assert d["config"]["global_batch"] == 200 and d["config"]["mode"] == "sync"
+    assert abs(d["value"] - 200 * 6 / (d["ms_per_step"] * 6 / 1e3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.slow
+def test_bench_exits_nonzero_when_a_worker_fails():
+    # an impossible configuration makes every worker raise; the parent must not print a result
+    r = _bench(["--gpus", "2", "--cpu", "--steps", "2", "--warmup", "0", "--config", "mlp_sync", "--optimizer", "nonsense"])
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_the_rehearsal_switch():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than two GPUs")
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "0"], {"DTF_SHARE_GPU": "0"})
+    assert r.returncode != 0 and "GPU" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["mlp_sync", "mlp_async"])
+def test_bench_starts_its_own_two_gpu_workers_sharing_the_gpu(config):
+    """Two ranks on the one GPU of the test box (gloo carries the process group, the peer-mapped kernels carry
+    the updates): the path the 8-GPU scaling run takes, launcher included."""
+    d = _one_json_line(_bench(["--gpus", "2", "--steps", "60", "--warmup", "20", "--config", config],
+                              {"DTF_SHARE_GPU": "1", "DTF_DIST_BACKEND": "gloo", "DTF_P2P_ALLREDUCE": "1", "DTF_PEER_ASYNC": "1"}))
+    assert d["n_gpus"] == 2 and d["steps"] == 60 and d["value"] > 0
+    assert d["config"]["global_batch"] == 200
