@@ -89,6 +89,14 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
         return state, prog, engine
 
     state, prog, engine = build()
+    prepared = False
+    if world == 1 and not force and device.type == "cuda" and prog.use_graphs and args.warmup > 0:
+        # one worker: nothing is decided during the warm-up, so the graphs of the warm-up AND of the timed run are
+        # captured before either (capture takes milliseconds of host time during which the GPU would fall idle and
+        # drop its clocks right in front of the timed region)
+        prog.prepare_graphs(args.warmup, graph_steps)
+        prog.prepare_graphs(args.steps, graph_steps, start_offset=args.warmup)
+        prepared = True
     _sync_all(device, world)
     # The warm-up doubles as the acceptance run of the peer-mapped transport on this machine: if any rank's wait
     # for a peer runs into its limit, EVERY rank rebuilds the job on RCCL and warms up again (one decision for all)
@@ -111,7 +119,8 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
             state, prog, engine = build()
             _sync_all(device, world)
             engine.run(args.warmup, graph_steps) if args.warmup > 0 else None
-    _prepare_graphs(prog, args, graph_steps, device)
+    if not prepared:
+        _prepare_graphs(prog, args, graph_steps, device)
     _sync_all(device, world)
     t0 = time.perf_counter()
     engine.run(args.steps, graph_steps)

@@ -115,6 +115,28 @@ struct DtfMlp2Peer {
   int pad_;
 };
 
+// Sharded peer exchange inside launch 2 (mode 4): the parameter-server state is split by training workgroup,
+// workgroup w (its weight-gradient tiles and the parameters under them) belonging to rank w % world.  Every rank
+// computes every tile; a non-owner stores its tile into the owner's inbox and raises a flag there (reduce-scatter
+// by direct stores over xGMI, one message per link), the owner adds the world contributions in rank order, applies
+// the update and stores the new parameter tile into every peer's outbox (all-gather by direct stores), and the
+// non-owners copy it into their replica.  Per rank and step: 2 x (world-1)/world of the gradient bytes leave over
+// world-1 different links, instead of (world-1) x all of them arriving; two dependent hops instead of one.
+// All regions have one layout, so the struct carries one base pointer per rank and the offsets.
+struct DtfMlp2Shard {
+  char* region[8];          // exported region of every rank (own rank: the local pointer)
+  const float* params_base; // start of the local flat parameter buffer: offsets inside in/outboxes are parameter offsets
+  int* err;                 // set to 1 when a wait ran into its time limit
+  long long inbox_off;      // bytes from a region's start to float inbox[8 source ranks][n]
+  long long outbox_off;     // ... to float outbox[n]
+  long long inflag_off;     // ... to int inflags[8 source ranks][DTF_MLP2_MAX_WG]
+  long long outflag_off;    // ... to int outflags[DTF_MLP2_MAX_WG]
+  long long n;              // floats per flat buffer
+  int rank, world;
+  unsigned timeout_ticks;   // of the 100 MHz constant clock
+  int pad_;
+};
+
 // Asynchronous push/pull inside launch 2 (mode 3; see the async section of p2p_allreduce.hip): every weight-
 // gradient tile is applied to the owner's master slice through its mapped pointer (read at the start of the
 // launch, written back minus lr * gradient: the lock-free read-modify-write of the reference's async mode) and
@@ -148,18 +170,22 @@ struct DtfMlp2Args {
   int q;                    // slot of this step, 0..2
   int loss_mode;
   int mode;                 // 0: store gradients, 1: theta -= lr * grad, 2: peer exchange (gradients -> slot, theta -= lr * sum over ranks),
-                            // 3: async push/pull (master -= lr * grad through the mapped slices, replica = master)
+                            // 3: async push/pull (master -= lr * grad through the mapped slices, replica = master),
+                            // 4: sharded peer exchange (tile -> owner's inbox, owner updates and stores the tile into every outbox)
   int log_cap;
   float lr, inv_b;
   unsigned x_bytes;         // bytes addressable from X
   DtfTailArgs tail;         // state, perm, n_train, gs_inc (its log / partial / ridx fields are not used)
   DtfMlp2Peer peer;         // mode 2 only
   DtfMlp2Async async_;      // mode 3 only
+  DtfMlp2Shard shard;       // mode 4 only
 };
 DTF_EXPORT int dtf_mlp2_fwd(const DtfMlp2Args* a, hipStream_t s);
 DTF_EXPORT int dtf_mlp2_bwd(const DtfMlp2Args* a, hipStream_t s);
 // Fills `out` for gradient slot `slot` of a connected peer-mapped communicator (dtf_p2p_create / dtf_p2p_connect).
 DTF_EXPORT int dtf_p2p_mlp2_peer(void* comm, int slot, double timeout_s, DtfMlp2Peer* out);
+// Fills `out` (except params_base) for the sharded exchange over the same communicator.
+DTF_EXPORT int dtf_p2p_mlp2_shard(void* comm, double timeout_s, DtfMlp2Shard* out);
 
 // C[M,N] = A[M,K] . B[N,K]^T with both operands k-contiguous (see gemm_tiled.hip).
 // dtype: 0 = fp32, 1 = bf16 (fp32 accumulate).  epilogue: 0 forward (+bias, ReLU, optional transposed copy Ct

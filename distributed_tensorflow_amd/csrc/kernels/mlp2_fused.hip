@@ -449,11 +449,13 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     bold = __builtin_nontemporal_load(mbptr);
   }
   int seq = 0;
-  if (MODE == 2) {
+  if (MODE == 2 || MODE == 4) {
     seq = p.ctr_snap[1] + 1;                        // number of this step, the same on every rank
     if (tid == 0) *peer_timeout = 0;
   }
-  if (MODE == 1 || MODE == 2) {
+  // mode 4: only the rank that owns this workgroup's tiles needs their old values
+  const bool owner4 = MODE == 4 && (wgid % p.shard.world) == p.shard.rank;      // workgroup-uniform
+  if (MODE == 1 || MODE == 2 || owner4) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 4 * g + r;
@@ -475,7 +477,7 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
   M2_STAMP(4, blockIdx.x);
   // (mode 2: waves without a tile go on to the barriers of the exchange; their loads are out of range, i.e. zero,
   // and every store below is guarded)
-  if (!has_tile && MODE != 2) return;
+  if (!has_tile && MODE != 2 && MODE != 4) return;
 
   // ---- the tile ----
   float bq[NRB][4];
@@ -521,6 +523,121 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     bsum += __shfl_xor(bsum, 32);
   }
   const bool b_lane = mt == 0 && g == 0 && bn_ok;
+  if (MODE == 4) {
+    // ---- sharded exchange: tile -> owner (reduce-scatter), updated tile -> everybody (all-gather) ----
+    const DtfMlp2Shard& sh = p.shard;
+    const int me = sh.rank, world = sh.world;
+    const int owner = wgid % world;
+    size_t woff[4];
+    bool wok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 4 * g + r;
+      wok[r] = row < Mo && bn_ok;
+      woff[r] = wok[r] ? (size_t)(Wt - sh.params_base) + (size_t)row * N + n0 + fr : 0;
+    }
+    const size_t boff = b_lane ? (size_t)(bt - sh.params_base) + n0 + fr : 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (!owner4) {
+      // my contribution into the owner's inbox (row `me`), then the flag: stores and flag are system scope on
+      // uncached memory, the flag leaves after every store of the workgroup has been acknowledged
+      float* in = reinterpret_cast<float*>(sh.region[owner] + sh.inbox_off) + (size_t)me * sh.n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (wok[r]) __hip_atomic_store(in + woff[r], gv[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (b_lane) __hip_atomic_store(in + boff, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_store(reinterpret_cast<int*>(sh.region[owner] + sh.inflag_off) + me * DTF_MLP2_MAX_WG + wgid, seq,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the owner's answer: this workgroup's tiles, updated, in MY outbox
+        int* f = reinterpret_cast<int*>(sh.region[me] + sh.outflag_off) + wgid;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
+          if (__builtin_amdgcn_s_memrealtime() - t0 > sh.timeout_ticks) {
+            *peer_timeout = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      }
+      __syncthreads();
+      if (*peer_timeout) {                          // parameters stay untouched; the host sees the flag
+        if (tid == 0) *sh.err = 1;
+        return;
+      }
+      const float* ob = reinterpret_cast<const float*>(sh.region[me] + sh.outbox_off);
+      float nv[4], nb = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nv[r] = __hip_atomic_load(ob + woff[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (b_lane) nb = __hip_atomic_load(ob + boff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (wok[r]) Wt[(size_t)(m0 + 4 * g + r) * N + n0 + fr] = nv[r];
+      if (b_lane) bt[n0 + fr] = nb;
+      M2_STAMP(6, blockIdx.x);
+      return;
+    }
+    // owner: wait for this workgroup's tiles of every peer (they sit in local memory), add in rank order
+    if (tid < world && tid != me) {
+      int* f = reinterpret_cast<int*>(sh.region[me] + sh.inflag_off) + tid * DTF_MLP2_MAX_WG + wgid;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > sh.timeout_ticks) {
+          *peer_timeout = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    if (*peer_timeout) {
+      if (tid == 0) *sh.err = 1;
+      return;
+    }
+    const float* inb = reinterpret_cast<const float*>(sh.region[me] + sh.inbox_off);
+    float pv[8][4], pb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float* src = inb + (size_t)(k < world ? k : me) * sh.n;      // rows beyond the group: read again, not added
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pv[k][r] = __hip_atomic_load(src + woff[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      pb[k] = __hip_atomic_load(src + boff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    float sv[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < world) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] += k == me ? gv[r] : pv[k][r];
+        sb += k == me ? bsum : pb[k];
+      }
+    float nv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nv[r] = wold[r] - p.lr * sv[r];
+    const float nb = bold - p.lr * sb;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < world && k != me) {
+        float* ob = reinterpret_cast<float*>(sh.region[k] + sh.outbox_off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (wok[r]) __hip_atomic_store(ob + woff[r], nv[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (b_lane) __hip_atomic_store(ob + boff, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (wok[r]) Wt[(size_t)(m0 + 4 * g + r) * N + n0 + fr] = nv[r];
+    if (b_lane) bt[n0 + fr] = nb;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < world && tid != me)
+      __hip_atomic_store(reinterpret_cast<int*>(sh.region[tid] + sh.outflag_off) + wgid, seq, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    M2_STAMP(6, blockIdx.x);
+    return;
+  }
   if (MODE == 2) {
     // ---- exchange with the same workgroup of every peer, then the averaged update ----
     const int me = p.peer.rank, world = p.peer.world;
@@ -641,7 +758,22 @@ static int mlp2_validate(const DtfMlp2Args* a) {
   if (!a || !a->X || !a->labels || !a->Xg || !a->labg || !a->ridx || !a->H || !a->zpart || !a->W2s || !a->ctr_snap || !a->wlog)
     return DTF_ERR_ARG;
   if (!a->W1 || !a->b1 || !a->W2 || !a->b2 || !a->tail.state) return DTF_ERR_ARG;
-  if (a->mode < 0 || a->mode > 3) return DTF_ERR_ARG;
+  if (a->mode < 0 || a->mode > 4) return DTF_ERR_ARG;
+  if (a->mode == 4) {
+    const DtfMlp2Shard& sh = a->shard;
+    if (sh.world < 1 || sh.world > 8 || sh.rank < 0 || sh.rank >= sh.world || !sh.err || !sh.params_base || sh.n <= 0)
+      return DTF_ERR_ARG;
+    for (int k = 0; k < sh.world; ++k)
+      if (!sh.region[k]) return DTF_ERR_ARG;
+    // the four parameter tensors must be views into the flat buffer whose offsets address the boxes
+    const float* lo = sh.params_base;
+    const float* hi = lo + sh.n;
+    if (a->W1 < lo || a->b1 < lo || a->W2 < lo || a->b2 < lo) return DTF_ERR_ARG;
+    if (a->W1 + (size_t)a->In * a->Hd > hi || a->b1 + a->Hd > hi || a->W2 + (size_t)a->Hd * a->C > hi || a->b2 + a->C > hi)
+      return DTF_ERR_SHAPE;
+    const int NTv = dtf_cdiv(a->Hd, 16);
+    if (dtf_cdiv(dtf_cdiv(a->In, 16) * NTv, 4) + dtf_cdiv(NTv, 4) > DTF_MLP2_MAX_WG) return DTF_ERR_SHAPE;
+  }
   if ((a->mode == 0 || a->mode == 2) && (!a->dW1 || !a->db1 || !a->dW2 || !a->db2)) return DTF_ERR_ARG;
   if (a->mode == 3) {
     const DtfMlp2Async& as = a->async_;
@@ -699,7 +831,8 @@ static void mlp2_launch_bwd(const DtfMlp2Args& a, int nblk, hipStream_t s) {
     case 0: mlp2_launch_bwd_mode<NJ, 0>(a, nblk, s); break;
     case 1: mlp2_launch_bwd_mode<NJ, 1>(a, nblk, s); break;
     case 2: mlp2_launch_bwd_mode<NJ, 2>(a, nblk, s); break;
-    default: mlp2_launch_bwd_mode<NJ, 3>(a, nblk, s); break;
+    case 3: mlp2_launch_bwd_mode<NJ, 3>(a, nblk, s); break;
+    default: mlp2_launch_bwd_mode<NJ, 4>(a, nblk, s); break;
   }
 }
 

@@ -45,6 +45,16 @@ inline float* slot_of(char* base, int64_t n, int slot) { return reinterpret_cast
 inline int* flags_of(char* base, int64_t n) { return reinterpret_cast<int*>(base + (size_t)kSlots * n * sizeof(float)); }
 inline int* wgflags_of(char* base, int64_t n) { return flags_of(base, n) + kSlots * kMaxPeers; }
 constexpr size_t kFlagInts = (size_t)kSlots * kMaxPeers * (1 + DTF_MLP2_MAX_WG);
+// Behind the slots and their flags, for the sharded exchange (mlp2_fused.hip, mode 4) and the general
+// aggregation kernel below: inbox[8][n] | outbox[n] | inflags[8][MAX_WG] | outflags[MAX_WG] | sync words.
+constexpr size_t kSyncInts = 256;           // arrival stamps, decisions, "done" marks of the general aggregation kernel
+inline size_t shard_base(int64_t n) { return ((size_t)kSlots * n * sizeof(float) + kFlagInts * sizeof(int) + 255) & ~(size_t)255; }
+inline size_t inbox_off(int64_t n) { return shard_base(n); }
+inline size_t outbox_off(int64_t n) { return inbox_off(n) + (size_t)kMaxPeers * n * sizeof(float); }
+inline size_t inflag_off(int64_t n) { return outbox_off(n) + (size_t)n * sizeof(float); }
+inline size_t outflag_off(int64_t n) { return inflag_off(n) + (size_t)kMaxPeers * DTF_MLP2_MAX_WG * sizeof(int); }
+inline size_t sync_off(int64_t n) { return (outflag_off(n) + (size_t)DTF_MLP2_MAX_WG * sizeof(int) + 255) & ~(size_t)255; }
+inline size_t region_bytes(int64_t n) { return sync_off(n) + kSyncInts * sizeof(int); }
 
 struct P2PKernelArgs {
   const float* data[kMaxPeers];   // slot of every rank (own rank: local pointer)
@@ -105,7 +115,7 @@ DTF_EXPORT void* dtf_p2p_create(int rank, int world, int64_t n_floats, char* han
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
   P2PComm* c = new P2PComm;
   c->rank = rank; c->world = world; c->n = n_floats;
-  c->bytes = (size_t)kSlots * n_floats * sizeof(float) + kFlagInts * sizeof(int);
+  c->bytes = region_bytes(n_floats);
   void* p = nullptr;
   if (hipExtMallocWithFlags(&p, c->bytes, hipDeviceMallocUncached) != hipSuccess) { delete c; return nullptr; }
   c->local = static_cast<char*>(p);
@@ -187,6 +197,27 @@ DTF_EXPORT int dtf_p2p_mlp2_peer(void* comm, int slot, double timeout_s, DtfMlp2
     out->wgflags[p] = wgflags_of(c->peer[p], c->n);
   }
   out->err = c->err;
+  out->rank = c->rank;
+  out->world = c->world;
+  const double ticks = timeout_s * 1e8;
+  out->timeout_ticks = ticks > 4.0e9 ? 4000000000u : (unsigned)ticks;
+  return DTF_OK;
+}
+
+DTF_EXPORT int dtf_p2p_mlp2_shard(void* comm, double timeout_s, DtfMlp2Shard* out) {
+  P2PComm* c = static_cast<P2PComm*>(comm);
+  if (!c || !out) return DTF_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  for (int p = 0; p < c->world; ++p) {
+    if (!c->peer[p]) return DTF_ERR_ARG;      // dtf_p2p_connect has not run
+    out->region[p] = c->peer[p];
+  }
+  out->err = c->err;
+  out->inbox_off = (long long)inbox_off(c->n);
+  out->outbox_off = (long long)outbox_off(c->n);
+  out->inflag_off = (long long)inflag_off(c->n);
+  out->outflag_off = (long long)outflag_off(c->n);
+  out->n = c->n;
   out->rank = c->rank;
   out->world = c->world;
   const double ticks = timeout_s * 1e8;

@@ -105,6 +105,7 @@ class MLPProgram:
         self.grad_slots = None            # optional: one flat gradient buffer per slot (peer-mapped all-reduce)
         self.peer_exchange = None         # optional: (per-slot Mlp2Peer structs, lr / R): launch 2 exchanges and updates
         self.async_push = None            # optional: (Mlp2Async, lr): launch 2 applies its gradients to the mapped masters
+        self.shard_exchange = None        # optional: (Mlp2Shard, lr / R): launch 2 sends tiles to their owner rank, which updates
         self._eval_buf: Dict = {}
         self._args = [self._build_args(q) for q in range(self.P)] if self.is_cuda else None
         self._started = False
@@ -139,7 +140,7 @@ class MLPProgram:
         out = {"head": head, "wgrad": wgrad, "items": items}
         if self.fused2:
             tail = ops.make_tail(st.state, perm=self.data.perm, batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
-            if self.fused or self.async_push is not None:
+            if self.fused or self.async_push is not None or self.shard_exchange is not None:
                 g = lambda n: None
             elif self.grad_slots is not None:
                 g = lambda n: st._view(self.grad_slots[q], n)      # gradients land in this slot's exported buffer
@@ -150,8 +151,10 @@ class MLPProgram:
                 self.ctr_snap, st.var("hid_w"), st.var("hid_b"), st.var("sm_w"), st.var("sm_b"), self.wlog, self.B, self.R,
                 self.loss_mode, q, tail, dw1=g("hid_w"), db1=g("hid_b"), dw2=g("sm_w"), db2=g("sm_b"),
                 lr=(st.lr if self.fused else self.async_push[1] if self.async_push is not None
+                    else self.shard_exchange[1] if self.shard_exchange is not None
                     else self.peer_exchange[1] if self.peer_exchange is not None else None),
                 peer=self.peer_exchange[0][q] if self.peer_exchange is not None else None,
+                shard=self.shard_exchange[0] if self.shard_exchange is not None else None,
                 async_push=self.async_push[0] if self.async_push is not None else None)
         return out
 
@@ -163,7 +166,7 @@ class MLPProgram:
         if any(t.numel() != self.state.grads.numel() or t.dtype != torch.float32 for t in slots):
             raise ValueError("gradient slots must match the flat gradient buffer")
         self.grad_slots = list(slots)
-        self.peer_exchange = None
+        self.peer_exchange = self.shard_exchange = None
         self._args = [self._build_args(q) for q in range(self.P)]
         self._schedules.clear()
         self._graphs.clear()
@@ -177,13 +180,25 @@ class MLPProgram:
         self.peer_exchange = (list(peers), float(lr_over_r))
         self._args = [self._build_args(q) for q in range(self.P)]
 
+    def use_sharded_exchange(self, shard, lr_over_r: float) -> None:
+        """Sync mode with the parameter-server state sharded over the ranks, inside the two-launch step: every training
+        workgroup of the backward launch sends its gradient tiles to the rank that owns them (``shard``: ``Mlp2Shard``),
+        the owner applies ``theta -= lr_over_r * sum over ranks`` and stores the new tiles into every replica."""
+        if not self.fused2 or self.fused:
+            raise ValueError("the sharded exchange needs the two-launch step without the fused local update")
+        self.shard_exchange = (shard, float(lr_over_r))
+        self.peer_exchange = self.grad_slots = self.async_push = None
+        self._args = [self._build_args(q) for q in range(self.P)]
+        self._schedules.clear()
+        self._graphs.clear()
+
     def use_async_push(self, async_struct, lr: float) -> None:
         """Async mode on the two-launch step: the backward launch applies ``lr * gradient`` to the mapped master
         slices (``async_struct``: ``Mlp2Async``) and keeps the result as the local replica; no gradients are stored."""
         if not self.fused2 or self.fused or self.gs_inc != 0:
             raise ValueError("the in-launch async push needs the two-launch step with global_step left to the ps")
         self.async_push = (async_struct, float(lr))
-        self.peer_exchange = self.grad_slots = None
+        self.peer_exchange = self.grad_slots = self.shard_exchange = None
         self._args = [self._build_args(q) for q in range(self.P)]
         self._schedules.clear()
         self._graphs.clear()
@@ -335,15 +350,18 @@ class MLPProgram:
             remaining -= n
             at += n
 
-    def prepare_graphs(self, n_steps: int, graph_steps: int = 64) -> None:
-        """Capture and instantiate, without launching anything, the hipGraphs the next ``run(n_steps, graph_steps)``
+    def prepare_graphs(self, n_steps: int, graph_steps: int = 64, start_offset: int = 0) -> None:
+        """Capture and instantiate, without launching anything, the hipGraphs a later ``run(n_steps, graph_steps)``
         will replay (a graph is keyed by its length and the buffer slot it starts on): set-up cost kept out of a
-        timed run.  The steps beyond the last whole graph become one graph of exactly that length."""
+        timed run.  The steps beyond the last whole graph become one graph of exactly that length.  ``start_offset``:
+        that run starts after this many further steps (a warm-up still to come), so that nothing but the warm-up
+        itself has to happen between preparing and timing."""
         if not self.use_graphs:
             return
         if not self._started:
             self.start()
         saved = self.steps_enqueued
+        self.steps_enqueued += start_offset
         try:
             for n in list(self._launch_sizes(n_steps, graph_steps, exact_tail=True)):
                 if n >= 2:

@@ -285,13 +285,15 @@ MLP2_ROWS = 128          # rows per slot of the gathered-batch buffer
 
 
 def build_mlp2_args(x, labels, xg, labg, ridx, hact, zpart, w2_snap, ctr_snap, w1, b1, w2, b2, wlog, batch, rows_total,
-                    loss_mode, slot, tail, lr=None, dw1=None, db1=None, dw2=None, db2=None, peer=None, async_push=None):
+                    loss_mode, slot, tail, lr=None, dw1=None, db1=None, dw2=None, db2=None, peer=None, async_push=None,
+                    shard=None):
     """Argument pack of the two-launch step (K1-K11 of the reference graph in two kernels) for buffer slot
     ``slot``.  ``lr`` given: SGD applied in the epilogue; otherwise the four gradients are stored.  ``peer``
     (an ``_lib.Mlp2Peer`` whose own slot holds the four gradient tensors) together with ``lr``: the backward
     launch exchanges gradient tiles with the peers and applies ``theta -= lr * sum over ranks``.  ``async_push``
     (an ``_lib.Mlp2Async``) together with ``lr``: the backward launch applies ``lr * gradient`` to the mapped master
-    slices and keeps the result as the local replica (async mode)."""
+    slices and keeps the result as the local replica (async mode).  ``shard`` (an ``_lib.Mlp2Shard``) together with
+    ``lr``: sharded exchange, every workgroup's tiles are summed and updated by their owner rank and redistributed."""
     in_dim, hd = w1.shape
     c = w2.shape[1]
     if not mlp2_eligible(in_dim, [hd], c, batch):
@@ -315,14 +317,16 @@ def build_mlp2_args(x, labels, xg, labg, ridx, hact, zpart, w2_snap, ctr_snap, w
         raise ValueError("mlp2: wide log must be [capacity, 64]")
     if ridx.dim() != 2 or ridx.shape[0] != MLP2_SLOTS or ridx.shape[1] < 2 * batch:
         raise ValueError("mlp2: row index table must be [3, >= 2B]")
-    fused = lr is not None and peer is None and async_push is None
-    if peer is not None and async_push is not None:
-        raise ValueError("mlp2: peer exchange and async push are different modes")
+    fused = lr is not None and peer is None and async_push is None and shard is None
+    if sum(x is not None for x in (peer, async_push, shard)) > 1:
+        raise ValueError("mlp2: peer exchange, sharded exchange and async push are different modes")
+    if shard is not None and lr is None:
+        raise ValueError("mlp2: the sharded exchange applies the update itself and needs lr (already divided by R)")
     if async_push is not None and lr is None:
         raise ValueError("mlp2: the async push applies the update itself and needs lr")
     if peer is not None and lr is None:
         raise ValueError("mlp2: the peer exchange applies the update itself and needs lr (already divided by R)")
-    if not fused and async_push is None and any(t is None for t in (dw1, db1, dw2, db2)):
+    if not fused and async_push is None and shard is None and any(t is None for t in (dw1, db1, dw2, db2)):
         raise ValueError("mlp2: gradient outputs missing")
     for name, t, shp in (("dw1", dw1, (in_dim, hd)), ("dw2", dw2, (hd, c))):
         if t is not None and tuple(t.shape) != shp:
@@ -341,7 +345,8 @@ def build_mlp2_args(x, labels, xg, labg, ridx, hact, zpart, w2_snap, ctr_snap, w
                          b2=b2.data_ptr(), dW1=_lib.ptr(dw1), db1=_lib.ptr(db1), dW2=_lib.ptr(dw2), db2=_lib.ptr(db2),
                          wlog=wlog.data_ptr(), In=in_dim, Hd=hd, C=c, B=batch, R=rows_total, ldx=x.stride(0),
                          ldh=hact.stride(0), ridx_len=ridx.shape[1], h_rows=hact.shape[0], q=slot, loss_mode=loss_mode,
-                         mode=3 if async_push is not None else (2 if peer is not None else (1 if fused else 0)),
+                         mode=4 if shard is not None else 3 if async_push is not None else (2 if peer is not None else (1 if fused else 0)),
+                         shard=shard if shard is not None else _lib.Mlp2Shard(),
                          async_=async_push if async_push is not None else _lib.Mlp2Async(),
                          log_cap=wlog.shape[0], lr=float(lr) if lr is not None else 0.0, inv_b=1.0 / batch,
                          x_bytes=_lib.span_bytes(x), tail=tail, peer=peer if peer is not None else _lib.Mlp2Peer())

@@ -101,6 +101,13 @@ class Mlp2Async(C.Structure):
                 ("slice", C.c_longlong), ("shards", C.c_int), ("pad_", C.c_int)]
 
 
+class Mlp2Shard(C.Structure):
+    """Mirror of ``DtfMlp2Shard``: regions of all ranks and the box / flag offsets of the sharded exchange."""
+    _fields_ = [("region", C.c_void_p * 8), ("params_base", C.c_void_p), ("err", C.c_void_p), ("inbox_off", C.c_longlong),
+                ("outbox_off", C.c_longlong), ("inflag_off", C.c_longlong), ("outflag_off", C.c_longlong), ("n", C.c_longlong),
+                ("rank", C.c_int), ("world", C.c_int), ("timeout_ticks", C.c_uint), ("pad_", C.c_int)]
+
+
 class Mlp2Args(C.Structure):
     _fields_ = [("X", C.c_void_p), ("labels", C.c_void_p), ("Xg", C.c_void_p), ("labg", C.c_void_p), ("ridx", C.c_void_p),
                 ("H", C.c_void_p), ("zpart", C.c_void_p), ("W2s", C.c_void_p), ("ctr_snap", C.c_void_p), ("W1", C.c_void_p),
@@ -108,7 +115,8 @@ class Mlp2Args(C.Structure):
                 ("dW2", C.c_void_p), ("db2", C.c_void_p), ("wlog", C.c_void_p), ("In", C.c_int), ("Hd", C.c_int),
                 ("C", C.c_int), ("B", C.c_int), ("R", C.c_int), ("ldx", C.c_int), ("ldh", C.c_int), ("ridx_len", C.c_int),
                 ("h_rows", C.c_int), ("q", C.c_int), ("loss_mode", C.c_int), ("mode", C.c_int), ("log_cap", C.c_int), ("lr", C.c_float),
-                ("inv_b", C.c_float), ("x_bytes", C.c_uint), ("tail", TailArgs), ("peer", Mlp2Peer), ("async_", Mlp2Async)]
+                ("inv_b", C.c_float), ("x_bytes", C.c_uint), ("tail", TailArgs), ("peer", Mlp2Peer), ("async_", Mlp2Async),
+                ("shard", Mlp2Shard)]
 
 
 OP_SMALL_GEMM, OP_HEAD, OP_WGRAD, OP_TAIL, OP_GEMM_TILED, OP_UPDATE, OP_MLP2_FWD, OP_MLP2_BWD = 1, 2, 3, 4, 5, 6, 7, 8

@@ -50,6 +50,8 @@ def _lib_k():
                                               C.c_void_p]
         lib.dtf_p2p_mlp2_peer.restype = C.c_int
         lib.dtf_p2p_mlp2_peer.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(_lib.Mlp2Peer)]
+        lib.dtf_p2p_mlp2_shard.restype = C.c_int
+        lib.dtf_p2p_mlp2_shard.argtypes = [C.c_void_p, C.c_double, C.POINTER(_lib.Mlp2Shard)]
         lib.dtf_p2p_error.restype = C.c_int
         lib.dtf_p2p_error.argtypes = [C.c_void_p]
         lib.dtf_p2p_destroy.restype = None
@@ -120,6 +122,16 @@ class P2PAllReduce:
         (``csrc/kernels/mlp2_fused.hip``, mode 2): no separate update launch."""
         out = _lib.Mlp2Peer()
         _lib.check(_lib_k().dtf_p2p_mlp2_peer(self._comm, slot, self.timeout_s, C.byref(out)), "p2p_mlp2_peer")
+        return out
+
+    def mlp2_shard(self, params: torch.Tensor) -> "_lib.Mlp2Shard":
+        """Regions and box offsets for the two-launch step's sharded exchange (``mlp2_fused.hip``, mode 4): workgroup w
+        belongs to rank ``w % world``, which sums the contributions, updates and redistributes the tiles."""
+        if params.numel() != self.n or params.dtype != torch.float32 or not params.is_contiguous():
+            raise ValueError("p2p sharded exchange: params must be the flat float32 buffer the boxes were sized for")
+        out = _lib.Mlp2Shard()
+        _lib.check(_lib_k().dtf_p2p_mlp2_shard(self._comm, self.timeout_s, C.byref(out)), "p2p_mlp2_shard")
+        out.params_base = params.data_ptr()
         return out
 
     def allreduce_sgd(self, slot: int, params: torch.Tensor, seq: torch.Tensor, scale: float,

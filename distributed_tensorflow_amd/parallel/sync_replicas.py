@@ -64,6 +64,15 @@ class SyncReplicasEngine:
             capture_collectives = os.environ.get("DTF_CAPTURE_COLLECTIVES", "0") == "1" or force_collectives
         self.capture_collectives = capture_collectives
         self.coll = Collectives(group) if self.use_coll else None
+        # Peer-mapped transports of the small-model step (one node): "replicated" = every rank reads every peer's
+        # gradient tiles and updates its own replica (one hop, (N-1) x all gradient bytes per rank), "sharded" = every
+        # tile is summed and updated by its owner rank and stored into every replica (two hops, 2 (N-1)/N of the
+        # bytes).  p2p_* name the wish; the library collective named next to it is what runs where peers cannot be mapped.
+        self._want_p2p = None
+        if collective == "p2p_sharded":
+            self._want_p2p, collective = "sharded", "reduce_scatter"
+        elif collective == "p2p_replicated":
+            self._want_p2p, collective = "replicated", "all_reduce"
         if collective == "auto":
             small = state.nbytes() < ALLREDUCE_BELOW_BYTES and state.optimizer == "sgd"
             collective = "all_reduce" if small else "reduce_scatter"
@@ -77,6 +86,11 @@ class SyncReplicasEngine:
         if collective == "all_reduce" and state.optimizer != "sgd":
             raise ValueError("the replicated all-reduce path is only defined for SGD")
         self.collective = collective
+        if self._want_p2p is None and collective == "all_reduce":
+            self._want_p2p = os.environ.get("DTF_P2P_MODE", "replicated")
+            if self._want_p2p not in ("replicated", "sharded"):
+                raise ValueError("DTF_P2P_MODE must be 'replicated' or 'sharded'")
+        self.p2p_mode = None                    # the peer-mapped transport in use, else None
         self.fast = self.R == self.world
         self.arrival_delay = arrival_delay      # test hook: artificial per-step compute delay of this rank
         self._rs_out = torch.empty(state.layout.shard_size, dtype=torch.float32, device=state.device) \
@@ -178,7 +192,7 @@ class SyncReplicasEngine:
         st, prog = self.state, self.program
         # "auto": real multi-rank RCCL groups only; "1": also one-rank groups and gloo rehearsals
         wanted = p2p.requested("") or (p2p.requested(self.coll.backend) and self.world > 1)
-        eligible = (self.collective == "all_reduce" and st.optimizer == "sgd" and self.world <= 8
+        eligible = (self._want_p2p is not None and st.optimizer == "sgd" and self.world <= 8
                     and getattr(prog, "fused2", False) and not prog.fused and prog.P == p2p.SLOTS)
         if not (wanted and eligible):
             return False
@@ -197,7 +211,11 @@ class SyncReplicasEngine:
             warnings.warn(f"peer-mapped all-reduce unavailable ({e}); using RCCL")
             return False
         self.p2p_fused = os.environ.get("DTF_P2P_FUSED", "1") != "0"
-        self._replica_checks_left = 1 if self.world > 1 else 0      # after the first run() (a warm-up, as a rule)
+        self.p2p_mode = self._want_p2p
+        # replicas are compared after the first run() (a warm-up, as a rule) and then every so many run() calls
+        self._replica_check_every = max(1, int(os.environ.get("DTF_REPLICA_CHECK_EVERY", "256")))
+        self._runs_since_check = 0
+        self._replica_checks_left = 1 if self.world > 1 else 0
         if os.environ.get("DTF_SHARE_GPU") == "1" and self.world > 3:
             # rehearsal with several ranks on ONE GPU: the waiting backward launches of the other ranks (108 workgroups
             # each) would occupy every CU, and a forward workgroup (1024 threads) needs a whole one - a deadlock that
@@ -209,7 +227,12 @@ class SyncReplicasEngine:
     def _wire_p2p(self) -> None:
         from . import p2p_allreduce as p2p
         st, prog = self.state, self.program
-        if self.p2p_fused:
+        if self.p2p_fused and self.p2p_mode == "sharded":
+            # the backward launch sends every tile to its owner rank, which updates it and stores it into every replica
+            prog.schedule_tail_fn = None
+            self._shard_struct = self.p2p.mlp2_shard(st.params)
+            prog.use_sharded_exchange(self._shard_struct, st.lr / self.R)
+        elif self.p2p_fused:
             # the backward launch exchanges gradient tiles with the peers and applies the update: two launches per step
             prog.schedule_tail_fn = None
             prog.use_peer_exchange(self.p2p.slots, [self.p2p.mlp2_peer(q) for q in range(prog.P)], st.lr / self.R)
@@ -221,6 +244,32 @@ class SyncReplicasEngine:
             prog.schedule_tail_fn = lambda q: [(p2p.OP_P2P_UPDATE, self._p2p_args[q], 0)]
         prog._schedules.clear()
         prog.after_compute = None
+
+    def set_p2p_mode(self, mode: str) -> None:
+        """Switch the peer-mapped transport between "replicated" and "sharded" (collective: every rank, between runs,
+        with the device idle).  Both work on the same mapped regions; parameters and counters carry over."""
+        if self.p2p is None:
+            raise RuntimeError("no peer-mapped transport is installed")
+        if mode not in ("replicated", "sharded"):
+            raise ValueError("mode must be 'replicated' or 'sharded'")
+        self.p2p_mode = mode
+        self._wire_p2p()
+
+    @property
+    def transport(self) -> str:
+        """What moves the gradients and parameters of a step between the ranks."""
+        if not self.use_coll:
+            return "none (one worker)"
+        if self.p2p is not None:
+            where = "inside the backward launch" if self.p2p_fused else "separate update launch"
+            if self.p2p_fused and self.p2p_mode == "sharded":
+                return "peer-mapped sharded exchange over xGMI (tile -> owner, updated tile -> every replica), " + where
+            return "peer-mapped replicated exchange over xGMI (every rank reads every peer's tiles), " + where
+        if self.bucketed is not None:
+            lib = "RCCL (native communicator)" if self.native_comm is not None else f"torch.distributed {self.coll.backend}"
+            return f"{lib} reduce-scatter / all-gather per bucket behind the backward pass"
+        lib = "RCCL (native communicator)" if self.native_comm is not None else f"torch.distributed {self.coll.backend}"
+        return f"{lib} " + ("all-reduce" if self.collective == "all_reduce" else "reduce-scatter + all-gather")
 
     def _check_replicas(self, late: bool = False) -> None:
         """After the first runs over peer-mapped buffers: every rank must hold bit-identical parameters (the kernels
@@ -283,7 +332,11 @@ class SyncReplicasEngine:
             self.updates_applied += n_steps
             if self.p2p is not None:
                 late = self.p2p.timed_out()
+                self._runs_since_check += 1
+                if self.world > 1 and self._runs_since_check >= self._replica_check_every:
+                    self._replica_checks_left = max(self._replica_checks_left, 1)      # periodic: same call count everywhere
                 if self._replica_checks_left > 0:
+                    self._runs_since_check = 0
                     self._check_replicas(late)      # collective: every rank learns of any rank's time-out
                 else:
                     if self.world > 1:              # one decision for all ranks (a 4-byte all-reduce per run() call)

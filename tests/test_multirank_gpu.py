@@ -31,7 +31,7 @@ def _sync_gpu(rank, world, port, collective, p2p=False, fused="1"):
     torch.cuda.synchronize()
     recs = prog.read_log(0, 20)
     out = {"params": st.params.cpu().numpy().copy(), "gs": st.global_step(), "first": recs[0].loss, "last": sum(r.loss for r in recs[-5:]) / 5.0,
-           "p2p": eng.p2p is not None, "fused": eng.p2p_fused}
+           "p2p": eng.p2p is not None, "fused": eng.p2p_fused, "mode": eng.p2p_mode, "transport": eng.transport}
     dist.barrier()
     dist.destroy_process_group()
     return out
@@ -119,6 +119,23 @@ def test_ranks_sync_with_peer_mapped_allreduce(world, fused):
     assert a["gs"] == b["gs"] == 21
     import numpy as np
     np.testing.assert_allclose(a["params"], c["params"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sync_with_sharded_peer_exchange(world):
+    """Parameter-server state sharded over the ranks inside the backward launch: every workgroup's tiles travel to
+    their owner rank, which sums them in rank order, updates and stores the new tiles into every replica; against
+    the same run over the process group's reduce-scatter / all-gather."""
+    res = run_ranks(_sync_gpu, world, "p2p_sharded", True, "1")
+    c = run_ranks(_sync_gpu, world, "reduce_scatter", False)[0]
+    assert all(r["p2p"] and r["fused"] and r["mode"] == "sharded" for r in res) and not c["p2p"]
+    assert "sharded" in res[0]["transport"]
+    for r in res[1:]:
+        assert (r["params"] == res[0]["params"]).all()          # every replica holds the owners' bits
+    assert all(r["gs"] == 21 for r in res)
+    import numpy as np
+    np.testing.assert_allclose(res[0]["params"], c["params"], rtol=1e-4, atol=1e-6)
+    assert res[0]["last"] < res[0]["first"] - 0.3
 
 
 def _peer_async_gpu(rank, world, port, shards, fused="0"):
@@ -371,7 +388,7 @@ def test_differing_replicas_fall_back_to_the_update_launch():
     assert (a[0] == b[0]).all() and a[3] == b[3] == 21
 
 
-def _sync_gpu_long(rank, world, port, steps):
+def _sync_gpu_long(rank, world, port, steps, collective="all_reduce"):
     os.environ["DTF_P2P_ALLREDUCE"] = "1"
     os.environ["DTF_P2P_FUSED"] = "1"
     from distributed_tensorflow_amd.data import mnist
@@ -384,7 +401,7 @@ def _sync_gpu_long(rank, world, port, steps):
     st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, lr=0.05)
     st.initialize(seed=3)
     prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=rank), 100, [100], fused_update=False)
-    eng = SyncReplicasEngine(prog, st, collective="all_reduce")
+    eng = SyncReplicasEngine(prog, st, collective=collective)
     assert eng.p2p_fused and prog.use_graphs
     done = 0
     while done < steps:                            # graph replays of 64 steps, ranks free-running between host checks
@@ -398,11 +415,11 @@ def _sync_gpu_long(rank, world, port, steps):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_peer_exchange_keeps_replicas_identical_over_thousands_of_graph_replayed_steps(world):
-    """Slots and flags are reused every third step and the ranks run ahead of each other by up to a step inside
-    the replayed graphs: after 4000 steps every replica must still hold the same bits."""
-    res = run_ranks(_sync_gpu_long, world, 4000, timeout=150)
+@pytest.mark.parametrize("world,collective", [(2, "all_reduce"), (3, "all_reduce"), (2, "p2p_sharded"), (3, "p2p_sharded")])
+def test_peer_exchange_keeps_replicas_identical_over_thousands_of_graph_replayed_steps(world, collective):
+    """Slots, boxes and flags are reused step after step and the ranks run ahead of each other by up to a step inside
+    the replayed graphs: after 4000 steps every replica must still hold the same bits (both transports)."""
+    res = run_ranks(_sync_gpu_long, world, 4000, collective, timeout=150)
     assert all(r[1] == 4001 for r in res), [r[1] for r in res]
     for i, r in enumerate(res[1:], 1):
         differ = int((r[0] != res[0][0]).sum())
