@@ -227,7 +227,7 @@ struct DtfGemmArgs {
 // in the reference runtime).  One call enqueues every entry in order on `s`; stops at the first error
 // and returns  (entry index << 8) | error code.
 enum { DTF_OP_SMALL_GEMM = 1, DTF_OP_HEAD = 2, DTF_OP_WGRAD = 3, DTF_OP_TAIL = 4, DTF_OP_GEMM_TILED = 5, DTF_OP_UPDATE = 6,
-       DTF_OP_MLP2_FWD = 7, DTF_OP_MLP2_BWD = 8, DTF_OP_P2P_UPDATE = 9, DTF_OP_ASYNC_PUSH_PULL = 10 };
+       DTF_OP_MLP2_FWD = 7, DTF_OP_MLP2_BWD = 8, DTF_OP_P2P_UPDATE = 9, DTF_OP_ASYNC_PUSH_PULL = 10, DTF_OP_P2P_SYNC_GENERAL = 11 };
 
 // Gradient aggregation + optimizer + parameter redistribution of one synchronous step.
 enum { DTF_UPDATE_LOCAL = 0, DTF_UPDATE_ALLREDUCE = 1, DTF_UPDATE_SHARDED = 2 };
@@ -268,6 +268,25 @@ struct DtfP2PUpdateArgs {
   float scale;            // lr / R
   int slot;               // 0..2, the slot the gradients of this step were written to
 };
+// One gradient contribution of the general SyncReplicas path (replicas_to_aggregate != workers), see p2p_allreduce.hip.
+struct DtfP2PGeneralArgs {
+  void* comm;             // dtf_p2p_create / dtf_p2p_connect
+  float* params;          // flat parameter replica, updated in place in the last round of an update
+  float* acc;             // flat accumulator over the rounds of an update
+  int* state;             // local counters: [0] global_step (+1 per update), [3] dropped gradients of this rank
+  int* wlog;              // optional wide log: record of the round gets [2] accepted mask, [3] dropped so far
+  const int* seq_ptr;     // device counter with the round number (identical on every rank, grows by one per round)
+  double timeout_s;       // wall-clock bound of every wait
+  double delay_s;         // test hook: this rank's contribution arrives this much later
+  float scale;            // lr / R
+  int slot;               // 0..2, the slot the gradients of this round were written to
+  int need;               // contributions the accumulator takes in this round
+  int first_round, last_round;
+  int stamp_offset;       // test hook: stamp = round number + stamp_offset
+  int log_cap;
+  int pad_;
+};
+DTF_EXPORT int dtf_p2p_sync_general(const DtfP2PGeneralArgs* u, hipStream_t s);
 DTF_EXPORT void* dtf_p2p_create(int rank, int world, int64_t n_floats, char* handle_out64);
 DTF_EXPORT int dtf_p2p_connect(void* comm, const char* all_handles);
 DTF_EXPORT float* dtf_p2p_slot_ptr(void* comm, int slot);
@@ -300,6 +319,8 @@ struct DtfScheduleEntry {
   const void* args;  // the op's argument struct
 };
 DTF_EXPORT int dtf_run_schedule(const DtfScheduleEntry* entries, int n, hipStream_t s);
+DTF_EXPORT int dtf_run_schedule_steps(const DtfScheduleEntry* const* per_slot, const int* counts, int nslots, int first_slot,
+                                      int n_steps, hipStream_t s);
 
 DTF_EXPORT int dtf_gemm_tiled(const DtfGemmArgs* a, hipStream_t s);
 DTF_EXPORT void dtf_gemm_set_modes(int big_tile, int pingpong);

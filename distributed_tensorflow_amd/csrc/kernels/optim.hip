@@ -247,9 +247,25 @@ DTF_EXPORT int dtf_run_schedule(const DtfScheduleEntry* entries, int n, hipStrea
       case DTF_OP_MLP2_BWD: rc = dtf_mlp2_bwd(static_cast<const DtfMlp2Args*>(entries[i].args), s); break;
       case DTF_OP_P2P_UPDATE: rc = dtf_p2p_update(static_cast<const DtfP2PUpdateArgs*>(entries[i].args), s); break;
       case DTF_OP_ASYNC_PUSH_PULL: rc = dtf_async_push_pull(static_cast<const DtfAsyncPushPullArgs*>(entries[i].args), s); break;
+      case DTF_OP_P2P_SYNC_GENERAL: rc = dtf_p2p_sync_general(static_cast<const DtfP2PGeneralArgs*>(entries[i].args), s); break;
       default: rc = DTF_ERR_ARG;
     }
     if (rc != DTF_OK) return (i << 8) | rc;
+  }
+  return DTF_OK;
+}
+
+// Several steps in one call: step i runs the schedule of slot (first_slot + i) % nslots.  Launching a short run
+// this way starts the device a few microseconds after the call (a graph replay of the same steps takes 10-16 us
+// to start) and the host stays ahead of the device as long as a kernel runs longer than its launch call.
+DTF_EXPORT int dtf_run_schedule_steps(const DtfScheduleEntry* const* per_slot, const int* counts, int nslots, int first_slot,
+                                      int n_steps, hipStream_t s) {
+  if (!per_slot || !counts || nslots <= 0 || first_slot < 0 || first_slot >= nslots || n_steps < 0) return DTF_ERR_ARG;
+  int q = first_slot;
+  for (int i = 0; i < n_steps; ++i) {
+    const int rc = dtf_run_schedule(per_slot[q], counts[q], s);
+    if (rc != DTF_OK) return rc;
+    q = q + 1 == nslots ? 0 : q + 1;
   }
   return DTF_OK;
 }

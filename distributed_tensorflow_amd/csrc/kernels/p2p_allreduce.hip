@@ -38,7 +38,7 @@ struct P2PComm {
   char* local = nullptr;
   char* peer[kMaxPeers] = {};
   bool opened[kMaxPeers] = {};
-  int* err = nullptr;      // device flag: 1 = a wait ran into its time limit
+  int* err = nullptr;      // device ints: [0] 1 = a wait ran into its time limit, [1] block counter of the general kernel
 };
 
 inline float* slot_of(char* base, int64_t n, int slot) { return reinterpret_cast<float*>(base) + (size_t)slot * n; }
@@ -119,8 +119,8 @@ DTF_EXPORT void* dtf_p2p_create(int rank, int world, int64_t n_floats, char* han
   void* p = nullptr;
   if (hipExtMallocWithFlags(&p, c->bytes, hipDeviceMallocUncached) != hipSuccess) { delete c; return nullptr; }
   c->local = static_cast<char*>(p);
-  if (hipMemset(p, 0, c->bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&c->err), sizeof(int)) != hipSuccess ||
-      hipMemset(c->err, 0, sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+  if (hipMemset(p, 0, c->bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&c->err), 4 * sizeof(int)) != hipSuccess ||
+      hipMemset(c->err, 0, 4 * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
     (void)hipFree(p);
     delete c;
     return nullptr;
@@ -202,6 +202,180 @@ DTF_EXPORT int dtf_p2p_mlp2_peer(void* comm, int slot, double timeout_s, DtfMlp2
   const double ticks = timeout_s * 1e8;
   out->timeout_ticks = ticks > 4.0e9 ? 4000000000u : (unsigned)ticks;
   return DTF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// SyncReplicas with replicas_to_aggregate != number of workers, on the device
+// (/root/reference/distributed.py:29-32, :92-100: ConditionalAccumulator + token queue).
+//
+// One launch per gradient contribution ("round"), after the backward launch has written the gradients into
+// the round's slot.  Round number c = the worker's local step, equal on every rank, and the stamp a
+// contribution carries:
+//   1. every rank stores its stamp into arrive[slot][rank] of the CHIEF's region (rank 0 hosts the accumulator);
+//   2. the chief takes the first `need` ranks whose stamp equals c - in the order its polls see them, lower
+//      rank first within one poll; a stamp older than c is stale and is never taken - and stores
+//      {c, accepted-rank mask} as ONE 8-byte word into decision[slot] of every rank's region;
+//   3. every rank waits for that word, adds the slots of the accepted ranks in rank order (identical replicas),
+//      accumulates over the rounds of an update and, in the update's last round, applies
+//      theta -= lr/R * sum and bumps global_step; a rank that finds itself outside the mask counts its
+//      gradient as dropped (device counter, also written to the step's log record);
+//   4. every rank stores c into done[rank] of every region, then waits until every rank has finished round
+//      c - 2: slots are reused every third round, so a rank may run at most two rounds ahead of the slowest
+//      (the reference's token queue is unbounded; ours holds two tokens per worker).
+// R < N: need = R, one round per update.  R > N: ceil(R/N) rounds per update, need = N except in the last.
+// No host involvement: graph-replayable.  Every wait is bounded by a wall-clock limit.
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr int kArriveOff = 0;        // int arrive[kSlots][kMaxPeers]
+constexpr int kDecisionOff = 32;     // 8-byte decision[kSlots] (ints 32..37)
+constexpr int kDoneOff = 48;         // int done[kMaxPeers]
+inline int* sync_of(char* base, int64_t n) { return reinterpret_cast<int*>(base + sync_off(n)); }
+
+struct P2PGeneralArgs {
+  const float* data[kMaxPeers];   // this round's slot of every rank
+  int* sync_peer[kMaxPeers];      // sync words of every rank's region
+  int* sync_local;
+  float* params;
+  float* acc;                     // local accumulator over the rounds of an update [n]
+  int* state;                     // local counters: [0] global_step, [3] gradients of this rank that were dropped
+  int* wlog;                      // optional wide log (DTF_WLOG_INTS ints per record): [2] accepted mask, [3] dropped so far
+  const int* seq_ptr;             // device counter holding the round number c
+  int* block_ctr;                 // local, monotonic: blocks that finished their share (last-block detection)
+  int* err;
+  int64_t n4;
+  int rank, world, slot;
+  int need, first_round, last_round;
+  int stamp_offset;               // test hook: the stamp published is c + stamp_offset (a stale contribution)
+  int log_cap;
+  unsigned delay_ticks;           // test hook: this rank's contribution arrives late by this much
+  unsigned timeout_ticks;
+  float scale;                    // lr / R
+};
+
+__device__ __forceinline__ bool p2p_wait_expired(unsigned long long t0, unsigned limit) {
+  return __builtin_amdgcn_s_memrealtime() - t0 > limit;
+}
+
+__global__ __launch_bounds__(256) void sync_general_kernel(P2PGeneralArgs a) {
+  __shared__ int sh_mask;
+  __shared__ int sh_timeout;
+  const int tid = threadIdx.x;
+  const int seq = *a.seq_ptr;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) {
+    sh_timeout = 0;
+    sh_mask = 0;
+    if (blockIdx.x == 0) {
+      if (a.delay_ticks) {
+        while (__builtin_amdgcn_s_memrealtime() - t0 < a.delay_ticks) __builtin_amdgcn_s_sleep(32);
+      }
+      // 1. my contribution (gradients complete: written by the launch before this one) and its stamp
+      __hip_atomic_store(a.sync_peer[0] + kArriveOff + a.slot * kMaxPeers + a.rank, seq + a.stamp_offset, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.rank == 0) {
+        // 2. the accumulator: first `need` fresh arrivals
+        int mask = 0, count = 0;
+        bool late = false;
+        while (count < a.need) {
+          for (int k = 0; k < a.world && count < a.need; ++k) {
+            if (mask >> k & 1) continue;
+            const int v = __hip_atomic_load(a.sync_local + kArriveOff + a.slot * kMaxPeers + k, __ATOMIC_ACQUIRE,
+                                            __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v == seq) { mask |= 1 << k; ++count; }
+          }
+          if (count >= a.need) break;
+          if (p2p_wait_expired(t0, a.timeout_ticks)) { late = true; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if (!late) {
+          const unsigned long long word = ((unsigned long long)(unsigned)seq << 32) | (unsigned)mask;
+          for (int k = 0; k < a.world; ++k)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.sync_peer[k] + kDecisionOff) + a.slot, word,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+    // 3. the decision of this round
+    const unsigned long long* d = reinterpret_cast<const unsigned long long*>(a.sync_local + kDecisionOff) + a.slot;
+    for (;;) {
+      const unsigned long long w = __hip_atomic_load(d, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((int)(w >> 32) == seq) { sh_mask = (int)(w & 0xffffffffu); break; }
+      if (p2p_wait_expired(t0, a.timeout_ticks)) { sh_timeout = 1; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  if (sh_timeout) {
+    if (tid == 0) *a.err = 1;
+    return;            // parameters stay untouched; the host sees the flag
+  }
+  const int mask = sh_mask;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < a.n4; i += stride) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < kMaxPeers; ++p)
+      if (p < a.world && (mask >> p & 1)) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.data[p]) + i);
+    f32x4* ac = reinterpret_cast<f32x4*>(a.acc) + i;
+    if (!a.first_round) s += *ac;
+    if (a.last_round) {
+      f32x4* q = reinterpret_cast<f32x4*>(a.params) + i;
+      *q = *q - a.scale * s;
+    } else {
+      *ac = s;
+    }
+  }
+  // 4. bookkeeping by the block that finishes last
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid != 0) return;
+  const int old = __hip_atomic_fetch_add(a.block_ctr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if ((old + 1) % (int)gridDim.x != 0) return;
+  if (!(mask >> a.rank & 1)) a.state[3] += 1;
+  if (a.last_round) a.state[0] += 1;               // one global_step increment per aggregated update
+  if (a.wlog) {
+    int* rec = a.wlog + (size_t)DTF_WLOG_INTS * ((seq - 1) % a.log_cap);
+    rec[2] = mask;
+    rec[3] = a.state[3];
+  }
+  for (int k = 0; k < a.world; ++k)
+    __hip_atomic_store(a.sync_peer[k] + kDoneOff + a.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int k = 0; k < a.world; ++k) {
+    while (__hip_atomic_load(a.sync_local + kDoneOff + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq - 2) {
+      if (p2p_wait_expired(t0, a.timeout_ticks)) { *a.err = 1; return; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+}  // namespace
+
+DTF_EXPORT int dtf_p2p_sync_general(const DtfP2PGeneralArgs* u, hipStream_t s) {
+  if (!u) return DTF_ERR_ARG;
+  P2PComm* c = static_cast<P2PComm*>(u->comm);
+  if (!c || !u->seq_ptr || !u->params || !u->acc || !u->state || u->slot < 0 || u->slot >= kSlots) return DTF_ERR_ARG;
+  if (u->need < 1 || u->need > c->world || u->scale != u->scale) return DTF_ERR_ARG;
+  if (!dtf_aligned16(u->params) || !dtf_aligned16(u->acc)) return DTF_ERR_ALIGN;
+  if (u->wlog && u->log_cap <= 0) return DTF_ERR_ARG;
+  P2PGeneralArgs a = {};
+  for (int p = 0; p < c->world; ++p) {
+    if (!c->peer[p]) return DTF_ERR_ARG;      // dtf_p2p_connect has not run
+    a.data[p] = slot_of(c->peer[p], c->n, u->slot);
+    a.sync_peer[p] = sync_of(c->peer[p], c->n);
+  }
+  a.sync_local = sync_of(c->local, c->n);
+  a.params = u->params; a.acc = u->acc; a.state = u->state; a.wlog = u->wlog; a.seq_ptr = u->seq_ptr;
+  a.block_ctr = c->err + 1; a.err = c->err;
+  a.n4 = c->n >> 2; a.rank = c->rank; a.world = c->world; a.slot = u->slot;
+  a.need = u->need; a.first_round = u->first_round; a.last_round = u->last_round; a.stamp_offset = u->stamp_offset;
+  a.log_cap = u->log_cap; a.scale = u->scale;
+  const double ticks = u->timeout_s * 1e8, dticks = u->delay_s * 1e8;
+  a.timeout_ticks = ticks > 4.0e9 ? 4000000000u : (unsigned)ticks;
+  a.delay_ticks = dticks > 4.0e9 ? 4000000000u : (dticks > 0 ? (unsigned)dticks : 0u);
+  // the grid size is fixed per communicator: the last-block detection counts in multiples of it
+  int grid = (int)((a.n4 + 255) / 256);
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(sync_general_kernel, dim3(grid), dim3(256), 0, s, a);
+  return dtf_check_launch();
 }
 
 DTF_EXPORT int dtf_p2p_mlp2_shard(void* comm, double timeout_s, DtfMlp2Shard* out) {

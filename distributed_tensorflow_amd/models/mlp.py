@@ -101,7 +101,9 @@ class MLPProgram:
         self._call_cache: Dict = {}
         self._schedules: Dict = {}
         self.schedule_tail_entries = []   # appended by the engine: the native update entry of each step
-        self.schedule_tail_fn = None      # optional: slot -> extra entries (an update entry that depends on the slot)
+        self.schedule_tail_fn = None      # optional: (slot, phase) -> extra entries (an update entry that depends on them)
+        self.phase_period = 1             # steps whose schedules differ beyond the buffer slot repeat with this period
+                                          # (phase of a step = local step % phase_period: rounds of a multi-round update)
         self.grad_slots = None            # optional: one flat gradient buffer per slot (peer-mapped all-reduce)
         self.peer_exchange = None         # optional: (per-slot Mlp2Peer structs, lr / R): launch 2 exchanges and updates
         self.async_push = None            # optional: (Mlp2Async, lr): launch 2 applies its gradients to the mapped masters
@@ -237,7 +239,8 @@ class MLPProgram:
     def _compute_schedule(self, q: int):
         """The whole compute part of a step (forward, head, backward, weight gradients + tail) as one
         native launch sequence; built once per step parity."""
-        sch = self._schedules.get(q)
+        phase = self.steps_enqueued % self.phase_period
+        sch = self._schedules.get((q, phase))
         if sch is None:
             st, rows, L = self.state, self.ridx[q], ops._lib
             entries = []
@@ -246,8 +249,8 @@ class MLPProgram:
                 entries = [(L.OP_MLP2_FWD, self._args[q]["mlp2"], 0), (L.OP_MLP2_BWD, self._args[q]["mlp2"], 0)]
                 entries.extend(self.schedule_tail_entries)
                 if self.schedule_tail_fn is not None:
-                    entries.extend(self.schedule_tail_fn(q))
-                sch = self._schedules[q] = L.Schedule(entries)
+                    entries.extend(self.schedule_tail_fn(q, phase))
+                sch = self._schedules[(q, phase)] = L.Schedule(entries)
                 return sch
             for l, name in enumerate(self.names):
                 entries.append((L.OP_SMALL_GEMM, ops.linear_fwd(x, st.var(f"{name}_w"), st.var(f"{name}_b"), True,
@@ -261,8 +264,10 @@ class MLPProgram:
                                                                      _build_only=True), 0))
             entries.append((L.OP_WGRAD, self._args[q]["wgrad"], 0))
             entries.extend(self.schedule_tail_entries)
+            if self.schedule_tail_fn is not None:
+                entries.extend(self.schedule_tail_fn(q, phase))
             sch = L.Schedule(entries)
-            self._schedules[q] = sch
+            self._schedules[(q, phase)] = sch
         return sch
 
     def enqueue_step(self) -> None:
@@ -314,8 +319,11 @@ class MLPProgram:
         dst[:self.B] = rows
 
     # ------------------------------------------------------------------ multi-step execution
+    def _graph_key(self, n: int, at: int):
+        return (n, at % self.P) if self.phase_period == 1 else (n, at % self.P, at % self.phase_period)
+
     def _graph_for(self, n: int):
-        key = (n, self.steps_enqueued % self.P)
+        key = self._graph_key(n, self.steps_enqueued)
         g = self._graphs.get(key)
         if g is None:
             saved = self.steps_enqueued
@@ -340,7 +348,7 @@ class MLPProgram:
             if self.use_graphs and remaining >= 2:
                 if remaining >= graph_steps:
                     n = graph_steps
-                elif exact_tail or (remaining, at % self.P) in self._graphs:
+                elif exact_tail or self._graph_key(remaining, at) in self._graphs:
                     n = remaining
                 else:
                     n = 1 << (remaining.bit_length() - 1)

@@ -142,6 +142,16 @@ class Schedule:
             raise RuntimeError(f"schedule entry {rc >> 8} refused its launch ({ERR_NAMES.get(rc & 0xff, rc & 0xff)})")
 
 
+def run_schedule_steps(schedules, first_slot: int, n_steps: int) -> None:
+    """``n_steps`` steps in ONE native call: step i runs ``schedules[(first_slot + i) % len(schedules)]``."""
+    n = len(schedules)
+    arr = (C.POINTER(ScheduleEntry) * n)(*[C.cast(s.array, C.POINTER(ScheduleEntry)) for s in schedules])
+    counts = (C.c_int * n)(*[s.n for s in schedules])
+    rc = kernels().dtf_run_schedule_steps(arr, counts, n, first_slot, n_steps, stream_handle())
+    if rc:
+        raise RuntimeError(f"schedule entry {rc >> 8} refused its launch ({ERR_NAMES.get(rc & 0xff, rc & 0xff)})")
+
+
 def span_bytes(t) -> int:
     """Bytes addressable from ``t.data_ptr()`` for a row-major 2-D (or 1-D) tensor view."""
     if t.dim() == 1:
@@ -172,6 +182,8 @@ def _declare_kernels(lib):
     lib.dtf_mlp2_fwd.argtypes = [C.POINTER(Mlp2Args), vp]
     lib.dtf_mlp2_bwd.argtypes = [C.POINTER(Mlp2Args), vp]
     lib.dtf_run_schedule.argtypes = [C.POINTER(ScheduleEntry), i32, vp]
+    lib.dtf_run_schedule_steps.argtypes = [C.POINTER(C.POINTER(ScheduleEntry)), C.POINTER(i32), i32, i32, i32, vp]
+    lib.dtf_run_schedule_steps.restype = i32
     lib.dtf_gather_cast_transpose.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     for name in ("dtf_small_gemm", "dtf_wgrad_grouped", "dtf_head", "dtf_step_tail", "dtf_sgd_apply", "dtf_adam_apply",
                  "dtf_truncated_normal", "dtf_accumulate", "dtf_kernels_abi_version", "dtf_gemm_tiled",

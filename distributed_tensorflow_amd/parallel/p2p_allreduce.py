@@ -23,6 +23,7 @@ import torch.distributed as dist
 from ..ops import _lib
 
 OP_P2P_UPDATE = 9
+OP_P2P_SYNC_GENERAL = 11
 SLOTS = 3
 HANDLE_BYTES = 64
 
@@ -30,6 +31,14 @@ HANDLE_BYTES = 64
 class P2PUpdateArgs(C.Structure):
     _fields_ = [("comm", C.c_void_p), ("params", C.c_void_p), ("sum_out", C.c_void_p), ("seq_ptr", C.c_void_p),
                 ("timeout_s", C.c_double), ("scale", C.c_float), ("slot", C.c_int)]
+
+
+class P2PGeneralArgs(C.Structure):
+    """Mirror of ``DtfP2PGeneralArgs``: one gradient contribution of the general SyncReplicas path."""
+    _fields_ = [("comm", C.c_void_p), ("params", C.c_void_p), ("acc", C.c_void_p), ("state", C.c_void_p), ("wlog", C.c_void_p),
+                ("seq_ptr", C.c_void_p), ("timeout_s", C.c_double), ("delay_s", C.c_double), ("scale", C.c_float),
+                ("slot", C.c_int), ("need", C.c_int), ("first_round", C.c_int), ("last_round", C.c_int),
+                ("stamp_offset", C.c_int), ("log_cap", C.c_int), ("pad_", C.c_int)]
 
 
 _declared = False
@@ -133,6 +142,24 @@ class P2PAllReduce:
         _lib.check(_lib_k().dtf_p2p_mlp2_shard(self._comm, self.timeout_s, C.byref(out)), "p2p_mlp2_shard")
         out.params_base = params.data_ptr()
         return out
+
+    def general_args(self, slot: int, params: torch.Tensor, acc: torch.Tensor, state: torch.Tensor, seq: torch.Tensor,
+                     scale: float, need: int, first_round: bool, last_round: bool, wlog: Optional[torch.Tensor] = None,
+                     delay_s: float = 0.0, stamp_offset: int = 0) -> P2PGeneralArgs:
+        """Schedule entry arguments of one contribution round of the general SyncReplicas path (``need`` of the ranks'
+        gradients are taken by the chief; the update is applied in the last round of an update)."""
+        for name, t in (("params", params), ("acc", acc)):
+            if t.numel() != self.n or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f"p2p general sync: {name} must be a flat float32 buffer of the slots' size")
+        if state.dtype != torch.int32 or state.numel() < 4:
+            raise ValueError("p2p general sync: state must hold at least 4 int32 counters")
+        if not 1 <= need <= self.world:
+            raise ValueError("p2p general sync: need must be within 1..world")
+        return P2PGeneralArgs(comm=self._comm, params=params.data_ptr(), acc=acc.data_ptr(), state=state.data_ptr(),
+                              wlog=_lib.ptr(wlog), seq_ptr=seq.data_ptr(), timeout_s=self.timeout_s, delay_s=float(delay_s),
+                              scale=float(scale), slot=slot, need=need, first_round=int(first_round),
+                              last_round=int(last_round), stamp_offset=int(stamp_offset),
+                              log_cap=0 if wlog is None else wlog.shape[0], pad_=0)
 
     def allreduce_sgd(self, slot: int, params: torch.Tensor, seq: torch.Tensor, scale: float,
                       sum_out: Optional[torch.Tensor] = None) -> None:

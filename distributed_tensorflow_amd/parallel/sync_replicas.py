@@ -45,7 +45,7 @@ class SyncReplicasEngine:
     def __init__(self, program, state: ShardedState, group=None, replicas_to_aggregate: Optional[int] = None,
                  total_num_replicas: Optional[int] = None, collective: str = "auto",
                  arrival_delay: Optional[Callable[[int], float]] = None, force_collectives: bool = False,
-                 capture_collectives: Optional[bool] = None):
+                 capture_collectives: Optional[bool] = None, device_delay_s: float = 0.0, stamp_offset: int = 0):
         self.program, self.state = program, state
         self.world = state.world_size
         self.total = total_num_replicas if total_num_replicas is not None else self.world
@@ -91,8 +91,13 @@ class SyncReplicasEngine:
             if self._want_p2p not in ("replicated", "sharded"):
                 raise ValueError("DTF_P2P_MODE must be 'replicated' or 'sharded'")
         self.p2p_mode = None                    # the peer-mapped transport in use, else None
-        self.fast = self.R == self.world
-        self.arrival_delay = arrival_delay      # test hook: artificial per-step compute delay of this rank
+        # DTF_FORCE_GENERAL_SYNC=1: R == workers through the general (stamped, chief-selected) path as well
+        self.fast = self.R == self.world and os.environ.get("DTF_FORCE_GENERAL_SYNC", "0") != "1"
+        self.arrival_delay = arrival_delay      # test hook: artificial per-step compute delay of this rank (host path)
+        self.device_delay_s = device_delay_s    # test hooks of the device path: this rank's contributions arrive late by
+        self.stamp_offset = stamp_offset        # this much / carry the stamp of an older round (stale)
+        self.rounds = max(1, -(-self.R // self.world))      # gradient contributions of a rank per aggregated update
+        self.general_on_device = False          # R != workers handled by the aggregation kernel, no host in the loop
         self._rs_out = torch.empty(state.layout.shard_size, dtype=torch.float32, device=state.device) \
             if self.use_coll else None
         self._acc = None
@@ -100,7 +105,7 @@ class SyncReplicasEngine:
         self.dropped = 0                        # gradients of THIS rank that were discarded as late
         if self.world == 1:
             # one rank: R gradients can only come from R successive batches on the same parameters
-            self.fast = self.R == 1
+            self.fast = self.R == 1 and self.fast
         self.bucketed = None
         if self.collective == "bucketed" and not (self.fast and not program.fused):
             self.collective = "reduce_scatter"      # the multi-round path aggregates whole gradients
@@ -112,6 +117,8 @@ class SyncReplicasEngine:
         self.p2p = None                         # peer-mapped one-shot all-reduce, else None
         self.p2p_fused = False                  # ... done by the backward launch itself (no update launch)
         self._update_schedule = None
+        if not self.fast:
+            self._try_install_general_p2p(group)
         if self.fast and not program.fused:
             program.after_compute = self._aggregate_and_apply if self.use_coll else (lambda: state.apply_shard(None, 1.0))
             # one rank: the optimizer of layer l beside the products of the layers below.  Opt-in: measured 2.83 ms
@@ -196,19 +203,7 @@ class SyncReplicasEngine:
                     and getattr(prog, "fused2", False) and not prog.fused and prog.P == p2p.SLOTS)
         if not (wanted and eligible):
             return False
-        hosts = [None] * self.world
-        dist.all_gather_object(hosts, socket.gethostname(), group=group)
-        if len(set(hosts)) != 1:
-            return False                            # peer mapping needs every rank on one node
-        n = st.grads.numel()
-        import warnings
-        if not p2p.P2PAllReduce.self_check(n, st.device, group):
-            warnings.warn("peer-mapped all-reduce failed its self-check on this machine; using RCCL")
-            return False
-        try:
-            self.p2p = p2p.P2PAllReduce(n, st.device, group)
-        except RuntimeError as e:                   # collective failure: raised on every rank
-            warnings.warn(f"peer-mapped all-reduce unavailable ({e}); using RCCL")
+        if not self._open_p2p(group):
             return False
         self.p2p_fused = os.environ.get("DTF_P2P_FUSED", "1") != "0"
         self.p2p_mode = self._want_p2p
@@ -222,6 +217,64 @@ class SyncReplicasEngine:
             # cannot occur with one rank per GPU.  The separate update launch waits with fewer workgroups.
             self.p2p_fused = False
         self._wire_p2p()
+        return True
+
+    def _open_p2p(self, group) -> bool:
+        """Map the peers' regions (collective; every rank gets the same answer): one node, self-check passed."""
+        from . import p2p_allreduce as p2p
+        import socket
+        import warnings
+        st = self.state
+        hosts = [None] * self.world
+        dist.all_gather_object(hosts, socket.gethostname(), group=group)
+        if len(set(hosts)) != 1:
+            return False                            # peer mapping needs every rank on one node
+        n = st.grads.numel()
+        if not p2p.P2PAllReduce.self_check(n, st.device, group):
+            warnings.warn("peer-mapped all-reduce failed its self-check on this machine; using RCCL")
+            return False
+        try:
+            self.p2p = p2p.P2PAllReduce(n, st.device, group)
+        except RuntimeError as e:                   # collective failure: raised on every rank
+            warnings.warn(f"peer-mapped all-reduce unavailable ({e}); using RCCL")
+            return False
+        return True
+
+    def _try_install_general_p2p(self, group) -> bool:
+        """replicas_to_aggregate != workers without the host: one aggregation kernel per gradient contribution behind
+        the backward launch (stamps, first-R selection by the chief, accepted-rank mask, multi-round accumulation:
+        ``sync_general_kernel`` in ``csrc/kernels/p2p_allreduce.hip``).  Needs the peer-mapped regions (one node, GPUs,
+        SGD, the two-launch step); otherwise the host path below remains."""
+        from . import native_comm as nc
+        from . import p2p_allreduce as p2p
+        st, prog = self.state, self.program
+        if not (self.coll is not None or dist.is_initialized()):
+            return False
+        if self.coll is None:
+            self.coll = Collectives(group)
+        wanted = p2p.requested("") or (p2p.requested(self.coll.backend) and self.world > 1)
+        eligible = (st.device.type == "cuda" and st.optimizer == "sgd" and self.world <= 8 and nc.enabled()
+                    and getattr(prog, "fused2", False) and not prog.fused and prog.P == p2p.SLOTS and prog.gs_inc == 0)
+        if not (wanted and eligible) or not self._open_p2p(group):
+            return False
+        W, R = self.world, self.R
+        self._acc = torch.zeros_like(st.grads)
+        prog.use_gradient_slots(self.p2p.slots)
+        prog.phase_period = self.rounds
+        seq = st.state[1:2]                         # local step after the tail's increment = number of the round
+        self._general_args = {}
+        for q in range(prog.P):
+            for ph in range(self.rounds):
+                self._general_args[(q, ph)] = self.p2p.general_args(
+                    q, st.params, self._acc, st.state, seq, st.lr / R, need=min(W, R - ph * W), first_round=ph == 0,
+                    last_round=ph == self.rounds - 1, wlog=getattr(prog, "wlog", None), delay_s=self.device_delay_s,
+                    stamp_offset=self.stamp_offset)
+        prog.schedule_tail_fn = lambda q, ph: [(p2p.OP_P2P_SYNC_GENERAL, self._general_args[(q, ph)], 0)]
+        prog._schedules.clear()
+        prog._graphs.clear()
+        prog.after_compute = None
+        self.general_on_device = True
+        self.p2p_mode = "general"
         return True
 
     def _wire_p2p(self) -> None:
@@ -241,7 +294,7 @@ class SyncReplicasEngine:
             # the step number the update kernel publishes: local_step after the tail's increment (equal on all ranks)
             seq = st.state[1:2]
             self._p2p_args = [self.p2p.update_args(q, st.params, seq, st.lr / self.R) for q in range(prog.P)]
-            prog.schedule_tail_fn = lambda q: [(p2p.OP_P2P_UPDATE, self._p2p_args[q], 0)]
+            prog.schedule_tail_fn = lambda q, phase: [(p2p.OP_P2P_UPDATE, self._p2p_args[q], 0)]
         prog._schedules.clear()
         prog.after_compute = None
 
@@ -258,6 +311,9 @@ class SyncReplicasEngine:
     @property
     def transport(self) -> str:
         """What moves the gradients and parameters of a step between the ranks."""
+        if self.general_on_device:
+            return ("peer-mapped aggregation kernel per contribution (stamped gradients, first-R selection by the chief, "
+                    "accepted-rank mask summed in rank order)")
         if not self.use_coll:
             return "none (one worker)"
         if self.p2p is not None:
@@ -347,8 +403,32 @@ class SyncReplicasEngine:
                     if late:
                         raise RuntimeError("peer-mapped all-reduce: a peer's gradients did not arrive within the time limit")
             return
+        if self.general_on_device:
+            # `rounds` program steps per update, every one of them compute launches + the aggregation kernel
+            self.program.run(n_steps * self.rounds, graph_steps)
+            self.updates_applied += n_steps
+            late = self.p2p.timed_out()
+            if self.world > 1:                      # one decision for all ranks
+                t = torch.tensor([1 if late else 0], dtype=torch.int32,
+                                 device=self.state.device if self.coll.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.coll.group)
+                late = bool(t.item())
+            if late:
+                raise RuntimeError("sync replicas: a wait for the chief's decision or for a peer ran into its time limit")
+            return
         for _ in range(n_steps):
             self._general_update()
+
+    @property
+    def dropped(self) -> int:
+        """Gradients of THIS rank that were computed but not aggregated (late or stale)."""
+        if self.general_on_device:
+            return int(self.state.state[3].item())
+        return self._dropped
+
+    @dropped.setter
+    def dropped(self, v: int) -> None:
+        self._dropped = v
 
     # ------------------------------------------------------------------ general path (R != num_workers)
     def _contribute(self):

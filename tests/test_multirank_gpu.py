@@ -424,3 +424,107 @@ def test_peer_exchange_keeps_replicas_identical_over_thousands_of_graph_replayed
     for i, r in enumerate(res[1:], 1):
         differ = int((r[0] != res[0][0]).sum())
         assert differ == 0, f"rank {i}: {differ} of {r[0].size} parameters differ from rank 0"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SyncReplicas with replicas_to_aggregate != workers on the device (stamped contributions, first-R selection by the
+# chief, multi-round accumulation; csrc/kernels/p2p_allreduce.hip: sync_general_kernel), against the NumPy oracle of
+# tests/test_sync_engine.py.  Ranks share the one GPU of the test box; an artificial DEVICE-side delay makes one rank late.
+# ------------------------------------------------------------------------------------------------------------------
+def _general_gpu(rank, world, port, R, steps, slow_rank, stale_rank=-1, graph_steps=4):
+    os.environ["DTF_P2P_ALLREDUCE"] = "1"
+    import oracle
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ds = mnist.synthetic_data_sets(train_size=600, validation_size=50, test_size=50, seed=100 + rank)
+    st = build_mlp_state(784, [16], 10, dev, world_size=world, rank=rank, lr=0.5)
+    init = oracle.init_params(16, seed=3)
+    st.load_values({k: torch.from_numpy(v).float() for k, v in init.items()})
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=100 + rank), 50, [16], fused_update=False, gs_inc=0,
+                      post_update_accuracy=False)
+    eng = SyncReplicasEngine(prog, st, replicas_to_aggregate=R, collective="all_reduce",
+                             device_delay_s=0.03 if rank == slow_rank else 0.0, stamp_offset=-1 if rank == stale_rank else 0)
+    assert eng.general_on_device and prog.use_graphs
+    dist.barrier()
+    eng.run(steps, graph_steps)                 # graph-replayed: no host between the rounds
+    torch.cuda.synchronize()
+    masks = prog.wlog.cpu()[:steps * eng.rounds, 2].tolist()
+    out = {"params": {n: st.var(n).cpu().numpy().copy() for n in st.names()}, "gs": st.global_step(), "ls": st.local_step(),
+           "dropped": eng.dropped, "masks": masks, "recs": [r.global_step for r in prog.read_log(0, steps * eng.rounds)]}
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def _oracle_run(contributions, R, steps):
+    """contributions(s) -> list of (rank, batch index) whose gradients update s averages."""
+    import numpy as np
+    import oracle
+    from distributed_tensorflow_amd.data import mnist
+    params = oracle.init_params(16, seed=3)
+    sets = {}
+    for s in range(steps):
+        grads = []
+        for rank, b in contributions(s):
+            if rank not in sets:
+                sets[rank] = mnist.synthetic_data_sets(train_size=600, validation_size=50, test_size=50, seed=100 + rank).train
+            rows = sets[rank].batch_rows(b * 50, 50)
+            x, y = sets[rank].images[rows].astype(np.float64), sets[rank].labels[rows].astype(np.float64)
+            grads.append(oracle.loss_and_grads(params, x, y)[2])
+        params = oracle.sgd(params, {k: sum(g[k] for g in grads) / R for k in params}, 0.5)
+    return params
+
+
+def _assert_params(res, want):
+    import numpy as np
+    for r in res[1:]:
+        for k in res[0]["params"]:
+            np.testing.assert_array_equal(r["params"][k], res[0]["params"][k])       # identical replicas
+    for k, v in want.items():
+        np.testing.assert_allclose(res[0]["params"][k], v, rtol=5e-4, atol=5e-6)
+
+
+def test_device_side_backup_worker_gradient_is_dropped_when_r_less_than_n():
+    world, R, steps, slow = 3, 2, 4, 2
+    res = run_ranks(_general_gpu, world, R, steps, slow)
+    assert res[slow]["dropped"] == steps and res[0]["dropped"] == 0 and res[1]["dropped"] == 0
+    assert all(m == 0b011 for m in res[0]["masks"])                 # the chief took ranks 0 and 1 every time
+    _assert_params(res, _oracle_run(lambda s: [(0, s), (1, s)], R, steps))
+    assert all(r["gs"] == 1 + steps and r["ls"] == steps for r in res)
+    assert res[0]["recs"] == list(range(1, steps + 1))              # global_step fetched with each step
+
+
+def test_device_side_r_greater_than_n_accumulates_several_rounds():
+    world, R, steps = 2, 3, 3          # every update: both workers once, then the faster one again
+    res = run_ranks(_general_gpu, world, R, steps, 1)
+    _assert_params(res, _oracle_run(lambda s: [(0, 2 * s), (1, 2 * s), (0, 2 * s + 1)], R, steps))
+    assert all(r["gs"] == 1 + steps and r["ls"] == 2 * steps for r in res)     # one increment per aggregate
+    assert res[1]["dropped"] == steps and res[0]["dropped"] == 0
+    assert res[0]["masks"] == [0b11, 0b01] * steps
+
+
+def test_device_side_stale_stamp_is_never_aggregated():
+    """A contribution that carries the stamp of an older round (a worker that computed on an old token) is dropped
+    by the accumulator, however early it arrives (ConditionalAccumulator semantics, distributed.py:97-100)."""
+    world, R, steps, stale = 3, 2, 3, 1
+    res = run_ranks(_general_gpu, world, R, steps, -1, stale)
+    assert res[stale]["dropped"] == steps and res[0]["dropped"] == 0 and res[2]["dropped"] == 0
+    assert all(m == 0b101 for m in res[0]["masks"])
+    _assert_params(res, _oracle_run(lambda s: [(0, s), (2, s)], R, steps))
+
+
+def test_device_side_general_path_with_r_equal_to_n_is_the_mean():
+    world, steps = 2, 5
+    # R == N goes through the fast path by default; the aggregation kernel must give the same mean when asked to
+    res = run_ranks(_general_forced, world, steps)
+    _assert_params(res, _oracle_run(lambda s: [(0, s), (1, s)], world, steps))
+
+
+def _general_forced(rank, world, port, steps):
+    os.environ["DTF_FORCE_GENERAL_SYNC"] = "1"
+    return _general_gpu(rank, world, port, world, steps, -1)
