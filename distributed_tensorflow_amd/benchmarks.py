@@ -56,6 +56,54 @@ def _max_over_ranks(value: float, device, world) -> float:
     return float(t.item())
 
 
+def _rccl_probe(engine, rank, world, device):
+    """How many ranks the native RCCL communicator of this job really has: its own count and an all-reduce of
+    ones through it (None off RCCL).  The communicator is the engine's when it made one, else a fresh one."""
+    if device.type != "cuda" or world < 1 or not dist.is_initialized() or dist.get_backend() != "nccl":
+        return None
+    from .parallel import native_comm as nc
+    if not nc.enabled():
+        return None
+    comm, own = getattr(engine, "native_comm", None), False
+    try:
+        if comm is None:
+            comm, own = nc.NativeComm(rank, world, device), True
+        ones = torch.ones(4, dtype=torch.float32, device=device)
+        comm.all_reduce_sum(ones)
+        torch.cuda.synchronize()
+        out = {"rccl_ranks": comm.count(), "rccl_allreduce_of_ones": float(ones[0].item())}
+        if own:
+            comm.destroy()
+        return out
+    except (RuntimeError, OSError) as e:
+        sys.stderr.write(f"[bench] rank {rank}: RCCL probe failed ({e})\n")
+        return None
+
+
+def _time_segment(engine, device, world, steps, graph_steps):
+    _sync_all(device, world)
+    t0 = time.perf_counter()
+    engine.run(steps, graph_steps)
+    _sync_all(device, world)
+    return _max_over_ranks(time.perf_counter() - t0, device, world)
+
+
+def _select_p2p_transport(engine, prog, args, rank, world, device, graph_steps):
+    """Both peer-mapped transports move the same step over the same mapped regions; which one is faster depends on
+    the machine (link latency against link bandwidth), so it is measured here: a short timed run of each, maximum
+    over the ranks, the faster one stays.  Returns the record that goes into the result line."""
+    trial = 192
+    times = {}
+    for mode in ("replicated", "sharded"):
+        engine.set_p2p_mode(mode)
+        engine.run(32, graph_steps)                         # captures the graphs, warms the path
+        times[mode] = _time_segment(engine, device, world, trial, graph_steps)
+    best = min(times, key=times.get)                        # the same on every rank: the times are maxima over the ranks
+    engine.set_p2p_mode(best)
+    return {"steps_each": trial, "replicated_us_per_step": times["replicated"] / trial * 1e6,
+            "sharded_us_per_step": times["sharded"] / trial * 1e6, "chosen": best}
+
+
 def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     batch = args.batch_size or (100 if not wide else 4096)
     hidden_units = args.hidden_units or (100 if not wide else 4096)
@@ -69,7 +117,9 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-    fused = world == 1 and optimizer == "sgd" and not wide and not force
+    R = getattr(args, "replicas_to_aggregate", None) or world
+    fast = R == world
+    fused = world == 1 and optimizer == "sgd" and not wide and not force and fast
     dtype_name = args.dtype or "fp32"
     graph_steps = args.graph_steps or 64
 
@@ -83,14 +133,26 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
             args.no_post_update_accuracy = True
         else:
             prog = MLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, fused_update=fused,
-                              post_update_accuracy=not args.no_post_update_accuracy, gs_inc=1)
+                              post_update_accuracy=not args.no_post_update_accuracy, gs_inc=1 if fast else 0)
         engine = SyncReplicasEngine(prog, state, collective=args.collective, force_collectives=force,
-                                    capture_collectives=False if force else None)
+                                    capture_collectives=False if force else None,
+                                    replicas_to_aggregate=getattr(args, "replicas_to_aggregate", None))
         return state, prog, engine
 
     state, prog, engine = build()
     prepared = False
-    if world == 1 and not force and device.type == "cuda" and prog.use_graphs and args.warmup > 0:
+    selection = None
+    extra_steps = 0                                         # steps of the transport trials (before the warm-up)
+    failed = 0
+    if (world > 1 and engine.p2p is not None and engine.p2p_fused and fast and args.collective == "auto"
+            and os.environ.get("DTF_P2P_MODE") is None):
+        try:
+            selection = _select_p2p_transport(engine, prog, args, rank, world, device, graph_steps)
+            extra_steps = 2 * (32 + selection["steps_each"])
+        except RuntimeError as e:                           # a peer wait ran into its limit: raised on every rank
+            sys.stderr.write(f"[bench] rank {rank}: transport trial failed ({e})\n")
+            failed, selection = 1, None
+    if world == 1 and not force and device.type == "cuda" and prog.use_graphs and args.warmup > 0 and fast:
         # one worker: nothing is decided during the warm-up, so the graphs of the warm-up AND of the timed run are
         # captured before either (capture takes milliseconds of host time during which the GPU would fall idle and
         # drop its clocks right in front of the timed region)
@@ -100,9 +162,9 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     _sync_all(device, world)
     # The warm-up doubles as the acceptance run of the peer-mapped transport on this machine: if any rank's wait
     # for a peer runs into its limit, EVERY rank rebuilds the job on RCCL and warms up again (one decision for all)
-    failed = 0
     try:
-        engine.run(args.warmup, graph_steps) if args.warmup > 0 else None
+        if not failed and args.warmup > 0:
+            engine.run(args.warmup, graph_steps)
     except RuntimeError as e:
         if engine.p2p is None or world == 1:
             raise
@@ -117,10 +179,11 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
             if device.type == "cuda":
                 torch.cuda.synchronize()
             state, prog, engine = build()
+            extra_steps = 0
             _sync_all(device, world)
             engine.run(args.warmup, graph_steps) if args.warmup > 0 else None
     if not prepared:
-        _prepare_graphs(prog, args, graph_steps, device)
+        _prepare_graphs(prog, args, graph_steps, device, 1 if engine.fast else engine.rounds)
     _sync_all(device, world)
     t0 = time.perf_counter()
     engine.run(args.steps, graph_steps)
@@ -128,38 +191,84 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     dt = time.perf_counter() - t0
     dt = _max_over_ranks(dt, device, world)
     gs = state.global_step()
-    assert gs == 1 + args.warmup + args.steps, (gs, args.warmup, args.steps)
+    assert gs == 1 + extra_steps + args.warmup + args.steps, (gs, extra_steps, args.warmup, args.steps)
     last = prog.read_log(prog.steps_enqueued - 1, 1)[0]
-    value = batch * args.steps * world / dt
-    return {
+    # examples per aggregated update: R gradients of `batch` examples each (distributed.py:92-100)
+    value = batch * args.steps * R / dt
+    probe = _rccl_probe(engine, rank, world, device) if world > 1 else None
+    second = None
+    if world > 1 and not wide and fast and not getattr(args, "no_second_mode", False):
+        # the other update mode of the same job, timed the same way, so that one invocation yields both numbers
+        transport = engine.transport
+        dropped = engine.dropped
+        if engine.p2p is not None:
+            torch.cuda.synchronize()
+            engine.p2p.close()
+        a2 = _async_args(args)
+        second = bench_mlp_async(a2, rank, world, device)
+        return _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer, dtype_name, R, dt, state, prog,
+                            engine, force, last, selection, probe, second, transport, dropped)
+    return _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer, dtype_name, R, dt, state, prog, engine,
+                        force, last, selection, probe, second, engine.transport, engine.dropped)
+
+
+def _async_args(args):
+    import copy
+    a = copy.copy(args)
+    a.config, a.optimizer = "mlp_async", None
+    return a
+
+
+def _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer, dtype_name, R, dt, state, prog, engine, force,
+                 last, selection, probe, second, transport, dropped):
+    value = batch * args.steps * R / dt
+    out = {
         "metric": METRIC, "value": value, "unit": "examples/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype_name if wide else "fp32", "data": "synthetic MNIST-shape (resident in HBM), random-init weights",
         "config": {"model": (f"wide_mlp 784-7x{hidden_units}-10" if wide else f"reference MLP 784-{hidden_units}-10"),
                    "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
-                   "parallelism": (f"dp{world} sync_replicas R={world}, " +
-                                   ("replicated SGD after one all-reduce (stateless optimizer, 318 KB of parameters)"
+                   "parallelism": (f"dp{world} sync_replicas R={R}, " +
+                                   (f"ps state sharded over {world} GPU(s) by weight-gradient tile (peer-mapped: tile -> owner, "
+                                    "updated tile -> every replica)" if engine.p2p_mode == "sharded" and engine.p2p_fused
+                                    else "replicated SGD after one all-reduce (stateless optimizer, 318 KB of parameters)"
                                     if (world > 1 or force) and engine.collective == "all_reduce"
                                     else f"ps state sharded over {world} GPU(s)")),
                    "optimizer": optimizer, "loss": "reference (softmax applied twice)", "mode": "sync",
                    "collective": engine.collective if (world > 1 or force) else "none",
+                   "transport": transport,
                    "native_rccl": engine.native_comm is not None,
                    "peer_mapped_allreduce": getattr(engine, "p2p", None) is not None,
+                   "peer_mapped_mode": engine.p2p_mode,
                    "peer_exchange_inside_backward_launch": bool(getattr(engine, "p2p_fused", False)) and getattr(engine, "p2p", None) is not None,
                    "post_update_accuracy_pass": not args.no_post_update_accuracy,
                    "hip_graph": bool(prog.use_graphs), "params": state.layout.used},
         "final_loss": last.loss,
     }
+    if R != world:
+        out["config"]["dropped_gradients_this_rank"] = dropped
+    if selection is not None:
+        out["config"]["transport_selection"] = selection
+    if probe is not None:
+        out.update(probe)
+    if second is not None:
+        out["async_value"] = second["value"]
+        out["async_ms_per_step"] = second["ms_per_step"]
+        out["async_config"] = second["config"]
+        for k in ("staleness_max", "staleness_mean", "global_step"):
+            if k in second:
+                out["async_" + k] = second[k]
+    return out
 
 
-def _prepare_graphs(prog, args, graph_steps, device) -> None:
+def _prepare_graphs(prog, args, graph_steps, device, steps_per_update: int = 1) -> None:
     """Build the hipGraphs of the timed run before the clock starts (after a warm-up run only: by then the engine
     has decided whether this program's steps are replayed at all).  Every timed step still runs inside the timed
     region; what moves out is graph capture and instantiation."""
     if args.warmup <= 0 or device.type != "cuda" or not getattr(prog, "use_graphs", False):
         return
     try:
-        prog.prepare_graphs(args.steps, graph_steps if graph_steps else 64)
+        prog.prepare_graphs(args.steps * steps_per_update, graph_steps if graph_steps else 64)
     except RuntimeError as e:
         sys.stderr.write(f"[bench] graphs not prepared ahead of the timed run ({e})\n")
         prog._graphs.clear()
@@ -221,6 +330,8 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
     # the wide model spreads its 416 MB of state over every rank (each owns a slice), the reference model keeps
     # the one logical ps shard of the named configuration
     shards = world if wide else 1
+    # reference behaviour: every step reads the ps-resident variables (staleness 0); --staleness k pulls every (k+1)-th step
+    staleness = args.staleness if getattr(args, "staleness", None) is not None else 0
     ds = mnist.synthetic_data_sets(train_size=train_rows, validation_size=100, test_size=100, seed=rank)
     state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer=optimizer, lr=lr)
     state.initialize(seed=1234)
@@ -243,7 +354,7 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
             os.environ.setdefault("MASTER_PORT", "29534")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
         prog = program(fused=False, gs_inc=0)
-        engine = PeerMappedAsyncEngine(prog, state, 1)
+        engine = PeerMappedAsyncEngine(prog, state, 1, staleness=staleness)
         finish = engine.finish
     elif world == 1:
         # one worker and its own ps: every update is applied before the next gradient is computed
@@ -252,7 +363,7 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
         finish = lambda: None
     else:
         prog = program(fused=False, gs_inc=0)
-        engine = make_async_engine(prog, state, shards, 4)
+        engine = make_async_engine(prog, state, shards, staleness)
         finish = engine.finish
     _sync_all(device, world)
     engine.run(args.warmup, 64)
@@ -265,19 +376,32 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
         engine.sync_params()
     _sync_all(device, world)
     dt = _max_over_ranks(time.perf_counter() - t0, device, world)
+    stale = None
+    if hasattr(engine, "staleness_stats"):
+        smax, smean = engine.staleness_stats(args.warmup, args.steps)
+        # every rank's view, worst case over the job
+        smax = int(_max_over_ranks(float(smax), device, world))
+        smean = _max_over_ranks(smean, device, world)
+        stale = (smax, smean)
     finish()
-    return {
+    out = {
         "metric": METRIC, "value": batch * args.steps * world / dt, "unit": "examples/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype_name,
         "data": "synthetic MNIST-shape (resident in HBM), random-init weights",
         "config": {"model": (f"wide_mlp 784-7x{hidden_units}-10" if wide else f"reference MLP 784-{hidden_units}-10"),
                    "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
-                   "parallelism": f"dp{world} async push/pull, {shards} ps shard(s), staleness {getattr(engine, 'staleness', 0)}",
+                   "parallelism": (f"dp{world} async push/pull, {shards} ps shard(s), pull every "
+                                   f"{getattr(engine, 'staleness', 0) + 1} step(s)"),
                    "optimizer": optimizer, "mode": "async", "engine": type(engine).__name__,
+                   "staleness_configured": getattr(engine, "staleness", 0),
                    "push_pull_inside_backward_launch": bool(getattr(engine, "fused", False)), "params": state.layout.used},
         "global_step": state.global_step() if rank == 0 else None,
     }
+    if stale is not None:
+        # measured on the device: updates of OTHER workers that the replica a gradient was computed on had not seen
+        out["staleness_max"], out["staleness_mean"] = stale
+    return out
 
 
 def run_benchmark(args):

@@ -253,6 +253,7 @@ DTF_EXPORT int dtf_comm_load(const char* path);
 DTF_EXPORT int dtf_comm_unique_id(char* out128);
 DTF_EXPORT void* dtf_comm_init(const char* id128, int nranks, int rank, int* rc_out);
 DTF_EXPORT int dtf_comm_destroy(void* comm);
+DTF_EXPORT int dtf_comm_count(void* comm);
 DTF_EXPORT const char* dtf_comm_error_string(int rc);
 DTF_EXPORT int dtf_comm_all_reduce_f32(void* comm, float* buf, int64_t count, hipStream_t s);
 DTF_EXPORT int dtf_comm_reduce_scatter_f32(void* comm, const float* send, float* recv, int64_t recvcount, hipStream_t s);
@@ -304,8 +305,16 @@ struct DtfAsyncPushPullArgs {
   int* state;             // local counters: state[0] receives global_step
   int64_t slice;          // floats per slice (multiple of 4)
   int shards;
-  int mode;               // 0: push (apply lr * grads) + pull, 1: pull only
+  int mode;               // 0: push (apply the optimizer to the masters) + pull, 1: pull only
   float lr;
+  int optimizer;          // 0 = SGD, 1 = Adam (moments m[], v[] next to the master slices)
+  float* m[8];            // Adam moments of slice s in the (mapped) region of its owner
+  float* v[8];
+  int* astate;            // optional local ints: [0] global_step at the last pull, [1] own pushes since
+  int* alog;              // optional ring [alog_cap][2]: {global_step after the push, updates of OTHER workers the replica missed}
+  int alog_cap;
+  int pull_every;         // pull on local steps divisible by this (<= 1: every step); other steps push only
+  float b1, b2, eps;
   int pad_;
 };
 DTF_EXPORT int dtf_async_push_pull(const DtfAsyncPushPullArgs* a, hipStream_t s);

@@ -431,17 +431,54 @@ DTF_EXPORT void dtf_p2p_destroy(void* comm) {
 // thread, no receive loop on the owner, nothing to wait for.
 // ------------------------------------------------------------------------------------------
 namespace {
+// Staleness bound: a worker pulls on the local steps divisible by `pull_every` (1 = every step) and pushes on every
+// step; between pulls it applies its own update to its replica, so the replica misses only the OTHER workers'
+// updates since its last pull.  How many those were when a gradient was pushed is logged per step.
+// Adam: the moments live next to the master slice in the owner's region (the slot variables of a ps-resident
+// optimizer) and are updated with the same lock-free read-modify-write; the bias correction uses the number of
+// updates the slice has received.
 __global__ __launch_bounds__(256) void async_push_pull_kernel(DtfAsyncPushPullArgs a) {
   const int64_t slice4 = a.slice >> 2;
   const int64_t total4 = slice4 * a.shards;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int ls = a.state[1];                     // local step, already advanced by the step's tail
+  const bool do_pull = a.mode == 1 || a.pull_every <= 1 || (ls % a.pull_every) == 0;
+  int cur_s = -1;
+  float lr_t = a.lr;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     const int s = (int)(i / slice4);
-    f32x4* m = reinterpret_cast<f32x4*>(a.master[s]) + (i - (int64_t)s * slice4);
+    const int64_t off = i - (int64_t)s * slice4;
+    f32x4* m = reinterpret_cast<f32x4*>(a.master[s]) + off;
     f32x4 v = __builtin_nontemporal_load(m);
     if (a.mode == 0) {
-      v -= a.lr * reinterpret_cast<const f32x4*>(a.grads)[i];
-      __builtin_nontemporal_store(v, m);
+      const f32x4 g = reinterpret_cast<const f32x4*>(a.grads)[i];
+      f32x4 nv;
+      if (a.optimizer == 0) {
+        nv = v - a.lr * g;
+      } else {
+        if (s != cur_s) {
+          cur_s = s;
+          const float t = (float)(__hip_atomic_load(a.counters[s] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1);
+          lr_t = a.lr * sqrtf(1.f - powf(a.b2, t)) / (1.f - powf(a.b1, t));
+        }
+        f32x4* mp = reinterpret_cast<f32x4*>(a.m[s]) + off;
+        f32x4* vp = reinterpret_cast<f32x4*>(a.v[s]) + off;
+        f32x4 mm = __builtin_nontemporal_load(mp), vv = __builtin_nontemporal_load(vp);
+        mm = a.b1 * mm + (1.f - a.b1) * g;
+        vv = a.b2 * vv + (1.f - a.b2) * (g * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nv[j] = v[j] - lr_t * mm[j] / (sqrtf(vv[j]) + a.eps);
+        __builtin_nontemporal_store(mm, mp);
+        __builtin_nontemporal_store(vv, vp);
+      }
+      __builtin_nontemporal_store(nv, m);
+      if (!do_pull) {
+        // push only: the replica takes this worker's own update and keeps missing the others'
+        f32x4* pl = reinterpret_cast<f32x4*>(a.params) + i;
+        *pl = *pl + (nv - v);
+        continue;
+      }
+      v = nv;
     }
     reinterpret_cast<f32x4*>(a.params)[i] = v;
   }
@@ -450,8 +487,20 @@ __global__ __launch_bounds__(256) void async_push_pull_kernel(DtfAsyncPushPullAr
     if (a.mode == 0) {
       gs = __hip_atomic_fetch_add(a.counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
       for (int s = 0; s < a.shards; ++s) __hip_atomic_fetch_add(a.counters[s] + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.astate) {
+        // astate[0] = global_step at this worker's last pull, astate[1] = its own pushes since then
+        const int unseen = gs - 1 - (a.astate[0] + a.astate[1]);
+        if (a.alog && a.alog_cap > 0) {
+          int* rec = a.alog + 2 * (size_t)((ls > 0 ? ls - 1 : 0) % a.alog_cap);
+          rec[0] = gs;
+          rec[1] = unseen < 0 ? 0 : unseen;
+        }
+        if (do_pull) { a.astate[0] = gs; a.astate[1] = 0; }
+        else a.astate[1] += 1;
+      }
     } else {
       gs = __hip_atomic_load(a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.astate) { a.astate[0] = gs; a.astate[1] = 0; }
     }
     a.state[0] = gs;      // global_step as the ps holds it after this worker's update
   }
@@ -461,13 +510,18 @@ __global__ __launch_bounds__(256) void async_push_pull_kernel(DtfAsyncPushPullAr
 DTF_EXPORT int dtf_async_push_pull(const DtfAsyncPushPullArgs* a, hipStream_t s) {
   if (!a || !a->params || !a->state || a->shards < 1 || a->shards > 8 || a->slice <= 0 || (a->slice & 3)) return DTF_ERR_ARG;
   if (a->mode == 0 && !a->grads) return DTF_ERR_ARG;
-  for (int i = 0; i < a->shards; ++i)
+  if (a->optimizer != 0 && a->optimizer != 1) return DTF_ERR_ARG;
+  if (a->alog && !a->astate) return DTF_ERR_ARG;
+  for (int i = 0; i < a->shards; ++i) {
     if (!a->master[i] || !a->counters[i]) return DTF_ERR_ARG;
+    if (a->optimizer == 1 && a->mode == 0 && (!a->m[i] || !a->v[i])) return DTF_ERR_ARG;
+  }
   if (!dtf_aligned16(a->params) || (a->grads && !dtf_aligned16(a->grads))) return DTF_ERR_ALIGN;
   const int64_t total4 = (a->slice >> 2) * a->shards;
-  int grid = (int)((total4 + 255) / 256);
-  if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(async_push_pull_kernel, dim3(grid), dim3(256), 0, s, *a);
+  // enough workgroups to keep the memory system busy on the 100 M-parameter model, one per 256 float4 on the small one
+  int64_t grid = (total4 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(async_push_pull_kernel, dim3((int)grid), dim3(256), 0, s, *a);
   return dtf_check_launch();
 }
 

@@ -26,6 +26,7 @@ struct Rccl {
   int (*GetUniqueId)(ncclUniqueId*) = nullptr;
   int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommCount)(ncclComm_t, int*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -49,7 +50,7 @@ DTF_EXPORT int dtf_comm_load(const char* path) {
   g_rccl.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
   if (!g_rccl.handle) return 1;
   bool ok = bind(g_rccl.GetUniqueId, "ncclGetUniqueId") && bind(g_rccl.CommInitRank, "ncclCommInitRank") &&
-            bind(g_rccl.CommDestroy, "ncclCommDestroy") && bind(g_rccl.AllReduce, "ncclAllReduce") &&
+            bind(g_rccl.CommDestroy, "ncclCommDestroy") && bind(g_rccl.CommCount, "ncclCommCount") && bind(g_rccl.AllReduce, "ncclAllReduce") &&
             bind(g_rccl.ReduceScatter, "ncclReduceScatter") && bind(g_rccl.AllGather, "ncclAllGather") &&
             bind(g_rccl.Broadcast, "ncclBroadcast") && bind(g_rccl.GetErrorString, "ncclGetErrorString");
   if (!ok) {
@@ -84,6 +85,12 @@ DTF_EXPORT void* dtf_comm_init(const char* id128, int nranks, int rank, int* rc_
 }
 
 DTF_EXPORT int dtf_comm_destroy(void* comm) { return (g_rccl.handle && comm) ? g_rccl.CommDestroy(comm) : -1; }
+// Number of ranks of the communicator as RCCL itself reports it (-1 on error).
+DTF_EXPORT int dtf_comm_count(void* comm) {
+  int n = -1;
+  if (!g_rccl.handle || !comm || g_rccl.CommCount(comm, &n) != 0) return -1;
+  return n;
+}
 DTF_EXPORT const char* dtf_comm_error_string(int rc) { return g_rccl.handle ? g_rccl.GetErrorString(rc) : "rccl not loaded"; }
 
 DTF_EXPORT int dtf_comm_all_reduce_f32(void* comm, float* buf, int64_t count, hipStream_t s) {

@@ -205,8 +205,9 @@ def define_framework_flags(fv: FlagValues = FLAGS) -> None:
                   "cross-entropy on the logits", fv)
     DEFINE_boolean('synthetic_data', False, 'Use a synthetic MNIST-shaped dataset instead of reading --data_dir', fv)
     DEFINE_integer('synthetic_train_size', 55000, 'Rows of the synthetic training set', fv)
-    DEFINE_integer('staleness', 4, 'Async mode: a worker never computes on parameters that miss more than this many of '
-                   'its own pushed updates', fv)
+    DEFINE_integer('staleness', 0, 'Async mode: a worker pushes its gradient on every step and refreshes its replica from '
+                   'the ps-resident parameters on every (staleness+1)-th; 0 = every step, as the reference (send/recv '
+                   'engine: pulls that may still be in flight when the next step starts)', fv)
     DEFINE_integer('log_every', 1, 'Print the per-step line every N local steps (reference: every step)', fv)
     DEFINE_integer('steps_per_launch', 0, 'Steps replayed per hipGraph launch (0 = choose automatically)', fv)
     DEFINE_integer('validation_every', 10000, 'Validate every N local steps (reference: 10000, including step 0)', fv)

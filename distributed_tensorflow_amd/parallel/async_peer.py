@@ -10,11 +10,21 @@ the usual compute launches followed by ONE kernel (``dtf_async_push_pull``) that
 every slice in place through the mapped pointers and keeps the fresh values as its local replica; the
 global-step counter sits next to shard 0 and is bumped with a system-scope atomic.  There is no service
 thread and no receive loop: owners are not involved in their peers' updates at all, which is exactly the
-lock-free semantics of the reference's ``use_locking=False``.  A pull is never older than the worker's own
-last step (staleness bound 0).
+lock-free semantics of the reference's ``use_locking=False``.
 
-``AsyncParameterServerEngine`` (send/recv, any backend, Adam) remains the general engine; this one is picked
-for SGD on one node with an RCCL process group after a start-up check on the actual machine
+Staleness: with ``staleness = k`` a worker pushes on every step and pulls on every (k+1)-th; in between it applies
+its own update to its replica, which therefore misses only the other workers' updates since its last pull.  The
+kernel logs, per step, how many such updates the master had received when the gradient was pushed
+(``staleness_stats``): the bound is measured, not assumed.  Adam keeps its moments next to the master slice in
+the owner's region (slot variables of a ps-resident optimizer), updated with the same lock-free read-modify-write.
+
+Steady state is free of collectives: ``run``, ``step`` and ``sync_params`` only launch kernels, so a worker that
+dies or leaves does not stall the others (workers talk to the ps shards, never to each other:
+``device_filters`` at distributed.py:116-117); ``finish`` waits for the others through the rendezvous store, with
+a time limit.
+
+``AsyncParameterServerEngine`` (send/recv, any backend, several nodes) remains the general engine; this one is
+picked on one node with an RCCL process group after a start-up check on the actual machine
 (``DTF_PEER_ASYNC=0`` disables, ``=1`` also allows gloo rehearsal groups).
 """
 from __future__ import annotations
@@ -36,9 +46,12 @@ COUNTER_BYTES = 64
 
 
 class AsyncPushPullArgs(C.Structure):
+    """Mirror of ``DtfAsyncPushPullArgs``."""
     _fields_ = [("master", C.c_void_p * 8), ("counters", C.c_void_p * 8), ("grads", C.c_void_p), ("params", C.c_void_p),
                 ("state", C.c_void_p), ("slice", C.c_int64), ("shards", C.c_int), ("mode", C.c_int), ("lr", C.c_float),
-                ("pad_", C.c_int)]
+                ("optimizer", C.c_int), ("m", C.c_void_p * 8), ("v", C.c_void_p * 8), ("astate", C.c_void_p),
+                ("alog", C.c_void_p), ("alog_cap", C.c_int), ("pull_every", C.c_int), ("b1", C.c_float), ("b2", C.c_float),
+                ("eps", C.c_float), ("pad_", C.c_int)]
 
 
 _declared = False
@@ -79,11 +92,14 @@ class PeerMappedUnavailable(RuntimeError):
 
 
 class PeerMappedAsyncEngine:
-    def __init__(self, program, state: ShardedState, num_shards: int = 1, group=None):
+    _instances = 0          # engines built so far in this process (the same on every rank): names the store keys
+
+    def __init__(self, program, state: ShardedState, num_shards: int = 1, group=None, staleness: int = 0,
+                 log_capacity: int = 4096):
         if program.fused or program.gs_inc != 0:
             raise ValueError("async mode needs a program that stores gradients and leaves global_step to the ps")
-        if state.optimizer != "sgd" or state.device.type != "cuda":
-            raise ValueError("the peer-mapped async engine implements plain SGD on GPUs")
+        if state.device.type != "cuda":
+            raise ValueError("the peer-mapped async engine runs on GPUs")
         self.program, self.state, self.group = program, state, group
         self.world, self.rank = state.world_size, state.rank
         self.device = state.device
@@ -93,7 +109,15 @@ class PeerMappedAsyncEngine:
             raise ValueError(f"{self.S} shards do not divide the flat buffer of {n} elements into 16-byte multiples")
         self.slice = n // self.S
         self.is_owner = self.rank < self.S
-        self.staleness = 0
+        self.adam = state.optimizer == "adam"
+        # A worker pulls every (staleness + 1)-th local step and pushes on every step; in between it applies its own
+        # update to its replica.  0 = pull with every push.
+        self.staleness = max(0, int(staleness))
+        # per local step {global_step after the push, updates of other workers the replica had not seen}: device ring
+        self.alog = torch.zeros((log_capacity, 2), dtype=torch.int32, device=self.device)
+        self._astate = torch.zeros(2, dtype=torch.int32, device=self.device)
+        PeerMappedAsyncEngine._instances += 1
+        self._key = f"dtf/async_peer/{PeerMappedAsyncEngine._instances}"
         self.updates_pushed = 0
         self.last_global_step = 1
         self._applied_final: Optional[int] = None
@@ -114,7 +138,8 @@ class PeerMappedAsyncEngine:
         good = len(set(hosts)) == 1 and self.world <= 8
         if good and self.is_owner:
             with torch.cuda.device(self.device):
-                self._local = lib.dtf_ipc_alloc(self.slice * 4 + COUNTER_BYTES, handle)
+                # [master slice | Adam m | Adam v | counters]: the moments are ps-resident like the variables
+                self._local = lib.dtf_ipc_alloc(self.slice * 4 * (3 if self.adam else 1) + COUNTER_BYTES, handle)
             good = bool(self._local)
         handles: List[Optional[bytes]] = [None] * self.world
         dist.all_gather_object(handles, bytes(handle.raw) if (self.is_owner and self._local) else b"", group=group)
@@ -149,12 +174,13 @@ class PeerMappedAsyncEngine:
         # two launches per step.  Measured on one rank: the launch then ends 2.9 us later (it has to see its stores
         # to the uncached master acknowledged), the separate push/pull kernel costs 3.9 us under the profiler and
         # 3.0 us in the step: 14.8 us/step either way, so the simpler sequence stays the default.
-        self.fused = bool(getattr(program, "fused2", False)) and os.environ.get("DTF_PEER_ASYNC_FUSED", "0") == "1"
+        self.fused = (bool(getattr(program, "fused2", False)) and os.environ.get("DTF_PEER_ASYNC_FUSED", "0") == "1"
+                      and self.staleness == 0 and not self.adam)
         if self.fused:
             a = _lib.Mlp2Async()
             for s in range(self.S):
                 a.master[s] = self._base[s]
-                a.counters[s] = self._base[s] + self.slice * 4
+                a.counters[s] = self._base[s] + self._counter_off
             a.params_base, a.slice, a.shards, a.pad_ = state.params.data_ptr(), self.slice, self.S, 0
             self._mlp2_async = a
             program.use_async_push(a, state.lr)
@@ -168,21 +194,43 @@ class PeerMappedAsyncEngine:
             program.after_compute = self._sched.run
 
     # ------------------------------------------------------------------ helpers
-    def _make_args(self, mode: int, lr: float) -> AsyncPushPullArgs:
+    @property
+    def _counter_off(self) -> int:
+        return self.slice * 4 * (3 if self.adam else 1)
+
+    def _make_args(self, mode: int, lr: float, check: bool = False) -> AsyncPushPullArgs:
+        """``check``: the start-up check's plain SGD push without staleness bookkeeping."""
         st = self.state
         a = AsyncPushPullArgs()
         for s in range(self.S):
             a.master[s] = self._base[s]
-            a.counters[s] = self._base[s] + self.slice * 4
+            a.counters[s] = self._base[s] + self._counter_off
+            if self.adam:
+                a.m[s] = self._base[s] + self.slice * 4
+                a.v[s] = self._base[s] + self.slice * 8
         a.grads, a.params, a.state = st.grads.data_ptr(), st.params.data_ptr(), st.state.data_ptr()
         a.slice, a.shards, a.mode, a.lr, a.pad_ = self.slice, self.S, mode, float(lr), 0
+        a.optimizer = 1 if (self.adam and not check) else 0
+        a.b1, a.b2, a.eps = st.beta1, st.beta2, st.eps
+        if check:
+            a.pull_every, a.astate, a.alog, a.alog_cap = 1, None, None, 0
+        else:
+            a.pull_every = self.staleness + 1
+            a.astate, a.alog, a.alog_cap = self._astate.data_ptr(), self.alog.data_ptr(), self.alog.shape[0]
         return a
 
     def _master_view(self) -> torch.Tensor:
         return torch.as_tensor(_DevicePtr(self._local, self.slice, "<f4"), device=self.device)
 
+    def moment_views(self):
+        """The owner-resident Adam moments (m, v) of this rank's slice, or None."""
+        if not (self.adam and self.is_owner and self._local):
+            return None
+        return (torch.as_tensor(_DevicePtr(self._local + self.slice * 4, self.slice, "<f4"), device=self.device),
+                torch.as_tensor(_DevicePtr(self._local + self.slice * 8, self.slice, "<f4"), device=self.device))
+
     def _counter_view(self) -> torch.Tensor:
-        return torch.as_tensor(_DevicePtr(self._local + self.slice * 4, COUNTER_BYTES // 4, "<i4"), device=self.device)
+        return torch.as_tensor(_DevicePtr(self._local + self._counter_off, COUNTER_BYTES // 4, "<i4"), device=self.device)
 
     def _barrier(self) -> None:
         if dist.get_backend(self.group) == "nccl":
@@ -200,7 +248,7 @@ class PeerMappedAsyncEngine:
         keep_p, keep_g, keep_s = st.params.clone(), st.grads.clone(), st.state.clone()
         ok = True
         try:
-            chk = self._make_args(0, 1.0)
+            chk = self._make_args(0, 1.0, check=True)
             for r in range(self.world):
                 if r == self.rank:
                     st.grads.fill_(float(r + 1))
@@ -227,8 +275,16 @@ class PeerMappedAsyncEngine:
         if self.is_owner:
             lo = self.rank * self.slice
             self._master_view().copy_(st.params[lo:lo + self.slice])
-            self._counter_view()[0:2] = torch.tensor([st.global_step() if self.rank == 0 else 0, 0], dtype=torch.int32,
+            applied = int(st.state[2].item()) if self.adam else 0      # Adam's update count (restored from a checkpoint)
+            self._counter_view()[0:2] = torch.tensor([st.global_step() if self.rank == 0 else 0, applied], dtype=torch.int32,
                                                       device=self.device)
+            mv = self.moment_views()
+            if mv is not None:
+                lo = self.rank * self.slice
+                own = (lo, lo + self.slice) == tuple(st.shard) and st.m is not None
+                mv[0].copy_(st.m) if own else mv[0].zero_()
+                mv[1].copy_(st.v) if own else mv[1].zero_()
+        self._astate.copy_(torch.tensor([st.global_step(), 0], dtype=torch.int32))
         torch.cuda.synchronize(self.device)
         self._barrier()
 
@@ -251,22 +307,61 @@ class PeerMappedAsyncEngine:
         self.last_global_step = self.state.global_step()
         return self.last_global_step
 
-    def finish(self) -> None:
+    def _store(self):
+        try:
+            return dist.distributed_c10d._get_default_store()
+        except (RuntimeError, AttributeError):
+            return None
+
+    def finish(self, timeout_s: float = 120.0) -> bool:
+        """This worker has pushed its last gradient.  Waits (bounded) until every worker has said the same through the
+        rendezvous store - not a collective: a worker that died never blocks the others' steps, and holds up their
+        ``finish`` for ``timeout_s`` at most.  Returns whether everybody reported.  An owner whose peers did not all
+        report keeps its slice allocated until the process ends (somebody may still be writing to it)."""
+        import time
         torch.cuda.synchronize(self.device)
-        self._barrier()                                   # nobody unmaps while a peer may still push
+        store = self._store()
+        everyone = store is not None
+        if store is not None:
+            store.set(f"{self._key}/done/{self.rank}", "1")
+            deadline = time.time() + timeout_s
+            for r in range(self.world):
+                while not store.check([f"{self._key}/done/{r}"]):
+                    if time.time() > deadline:
+                        everyone = False
+                        break
+                    time.sleep(0.01)
         self._launch(self._pull)
         torch.cuda.synchronize(self.device)
         if self.is_owner:
             self._applied_final = int(self._counter_view()[1].item())
-        self._barrier()
-        self._release()
+            mv = self.moment_views()
+            lo = self.rank * self.slice
+            if mv is not None and self.state.m is not None and (lo, lo + self.slice) == tuple(self.state.shard):
+                self.state.m.copy_(mv[0])                # the slot variables come home for the final checkpoint
+                self.state.v.copy_(mv[1])
+                self.state.state[2] = self._applied_final
+        self._release(free_local=everyone)
+        return everyone
 
-    def _release(self) -> None:
+    def staleness_stats(self, first_local_step: int, count: int):
+        """(max, mean) over local steps ``[first, first+count)`` of the number of other workers' updates that the replica
+        a gradient was computed on had not seen when the gradient was pushed.  Synchronises with the device."""
+        cap = self.alog.shape[0]
+        count = min(count, cap)
+        if count <= 0:
+            return 0, 0.0
+        log = self.alog.cpu()
+        idx = [(first_local_step + i) % cap for i in range(count)]
+        vals = log[idx, 1].to(torch.float64)
+        return int(vals.max().item()), float(vals.mean().item())
+
+    def _release(self, free_local: bool = True) -> None:
         lib = _lib_k()
         for p in self._mapped:
             lib.dtf_ipc_close(p)
         self._mapped = []
-        if self._local:
+        if self._local and free_local:
             lib.dtf_ipc_free(self._local)
             self._local = None
 
@@ -281,11 +376,11 @@ def make_async_engine(program, state: ShardedState, num_shards: int, staleness: 
     """The device-side engine where it applies (one node, SGD, GPUs, RCCL group), else the send/recv engine."""
     from .async_ps import AsyncParameterServerEngine
     import warnings
-    if (state.device.type == "cuda" and state.optimizer == "sgd" and state.world_size > 1 and state.world_size <= 8
+    if (state.device.type == "cuda" and state.world_size > 1 and state.world_size <= 8
             and state.layout.total % (4 * max(1, min(num_shards, state.world_size))) == 0
             and wanted(dist.get_backend(group), state.world_size) and _lib.kernels_available()):
         try:
-            return PeerMappedAsyncEngine(program, state, num_shards, group)
+            return PeerMappedAsyncEngine(program, state, num_shards, group, staleness=staleness)
         except PeerMappedUnavailable as e:                 # raised on every rank together
             warnings.warn(f"peer-mapped async engine unavailable ({e}); using send/recv")
     return AsyncParameterServerEngine(program, state, num_shards=num_shards, staleness=staleness)

@@ -39,6 +39,8 @@ def _lib_k():
         lib.dtf_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
         lib.dtf_comm_destroy.restype = C.c_int
         lib.dtf_comm_destroy.argtypes = [C.c_void_p]
+        lib.dtf_comm_count.restype = C.c_int
+        lib.dtf_comm_count.argtypes = [C.c_void_p]
         lib.dtf_comm_error_string.restype = C.c_char_p
         lib.dtf_comm_error_string.argtypes = [C.c_int]
         for name in ("dtf_comm_all_reduce_f32",):
@@ -101,6 +103,10 @@ class NativeComm:
     def _check(self, rc, what):
         if rc:
             raise RuntimeError(f"{what}: {self._lib.dtf_comm_error_string(rc).decode()}")
+
+    def count(self) -> int:
+        """Ranks of the communicator as RCCL reports them (``ncclCommCount``)."""
+        return int(self._lib.dtf_comm_count(self.handle))
 
     def all_reduce_sum(self, t: torch.Tensor) -> None:
         self._check(self._lib.dtf_comm_all_reduce_f32(self.handle, t.data_ptr(), t.numel(), _lib.stream_handle()), "all_reduce")

@@ -82,6 +82,9 @@ class TrainingLoop:
         self.keep_records = False
         self.validation_accuracies: List[float] = []
         self.stop_check = None                   # optional callable: True once the engine was told to stop
+        # Gradient contributions (= program steps = the reference's local steps) per aggregated update: more than one
+        # when replicas_to_aggregate exceeds the number of workers.  engine.run(n) runs n updates.
+        self.rounds = 1 if getattr(engine, "fast", True) else max(1, int(getattr(engine, "rounds", 1)))
 
     def _print_record(self, r: StepRecord) -> None:
         if self.keep_records:
@@ -107,7 +110,8 @@ class TrainingLoop:
             remaining = max(1, self.train_steps - last_seen_gs + 1)
         cap = self.steps_per_launch if self.steps_per_launch > 0 else 256
         cap = min(cap, self.prog.log_cap - 1, self.prog.data.max_steps_per_launch(self.prog.B))
-        return max(1, min(cap, remaining, to_validation))
+        # cap and to_validation count local steps, `remaining` counts updates
+        return max(1, min(cap // self.rounds, remaining, to_validation // self.rounds))
 
     def run(self) -> float:
         prog = self.prog
@@ -123,10 +127,11 @@ class TrainingLoop:
                     held = None
                 with trace.annotate("validation"):
                     self._validate()
-            n = self._plan(gs_seen)
+            n_updates = self._plan(gs_seen)
             first = self.local_step
-            with trace.annotate(f"launch {n} steps"):
-                self.engine.run(n, min(n, 64) if n >= 2 else 1)
+            with trace.annotate(f"launch {n_updates} updates"):
+                self.engine.run(n_updates, min(n_updates * self.rounds, 64) if n_updates * self.rounds >= 2 else 1)
+            n = n_updates * self.rounds
             if self.stop_check is not None and self.stop_check():
                 n = prog.steps_enqueued - first  # the service ended training: keep what actually ran
                 done = True
@@ -141,7 +146,8 @@ class TrainingLoop:
                 self._print_record(held)
                 held = None
             for i, r in enumerate(recs):
-                stop_here = r.global_step >= self.train_steps
+                # the stop rule is evaluated where an update completes (every step, unless an update takes several)
+                stop_here = r.global_step >= self.train_steps and (i + 1) % self.rounds == 0
                 if prog.post and r.post_correct is None:          # only the last record of a launch
                     if not stop_here:
                         held = r
@@ -166,7 +172,7 @@ class TrainingLoop:
 def build_worker(role: Optional[Role], device: torch.device, datasets, hidden_units: int, batch_size: int,
                  learning_rate: float, sync_replicas: bool, replicas_to_aggregate: Optional[int], world: int, rank: int,
                  optimizer: str = "sgd", loss: str = "reference", post_update_accuracy: bool = True, hidden_layers: int = 1,
-                 staleness: int = 4, num_ps: int = 1, seed: int = 0, collective: str = "auto", model: str = "mlp",
+                 staleness: int = 0, num_ps: int = 1, seed: int = 0, collective: str = "auto", model: str = "mlp",
                  dtype: str = "fp32"):
     """Graph construction of distributed.py:60-102, as device-side state + step program + engine."""
     if model not in ("mlp", "wide_mlp"):

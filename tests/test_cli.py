@@ -101,3 +101,31 @@ def test_three_workers_async_counts_all_updates():
         assert all(g <= 40 + 3 * 3 for g in gs)
     # global_step counts the updates of all workers: nobody needs 40 local steps
     assert 40 <= total_steps <= 40 + 3 * 4
+
+
+def test_one_worker_sync_r3_logs_every_contribution_and_counts_updates():
+    """replicas_to_aggregate=3 on one worker: three gradient contributions (local steps) per aggregated update;
+    every contribution prints its line with the global_step fetched with it, and exactly train_steps updates run."""
+    lines = _finish(_launch(["--job_name=worker", "--task_index=0", "--worker_hosts=127.0.0.1:%d" % free_port(),
+                             "--ps_hosts=", "--train_steps=7", "--sync_replicas", "--replicas_to_aggregate=3"] + COMMON))
+    steps = _steps(lines)
+    assert [s[0] for s in steps] == list(range(1, 22))                       # 7 updates x 3 contributions
+    assert [s[1] for s in steps] == [1 + i // 3 for i in range(21)]          # one increment per aggregate
+    assert steps[-1][2] < steps[0][2]
+
+
+@pytest.mark.slow
+def test_two_workers_sync_r3_runs_exactly_train_steps_updates():
+    port_w0, port_w1, port_ps = free_port(), free_port(), free_port()
+    hosts = ["--ps_hosts=127.0.0.1:%d" % port_ps, "--worker_hosts=127.0.0.1:%d,127.0.0.1:%d" % (port_w0, port_w1),
+             "--sync_replicas", "--replicas_to_aggregate=3", "--train_steps=6"] + COMMON
+    ps = _launch(["--job_name=ps", "--task_index=0"] + hosts)
+    w1 = _launch(["--job_name=worker", "--task_index=1"] + hosts)
+    w0 = _launch(["--job_name=worker", "--task_index=0"] + hosts)
+    l0, l1, _ = _finish(w0), _finish(w1), _finish(ps)
+    for st in (_steps(l0), _steps(l1)):
+        assert [s[0] for s in st] == list(range(1, 13))                      # 6 updates x 2 rounds per worker
+        assert [s[1] for s in st] == [1 + i // 2 for i in range(12)]
+    t0 = [l for l in l0 if "test accuracy" in l][0].split()[-1]
+    t1 = [l for l in l1 if "test accuracy" in l][0].split()[-1]
+    assert t0 == t1

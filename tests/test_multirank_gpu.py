@@ -528,3 +528,91 @@ def test_device_side_general_path_with_r_equal_to_n_is_the_mean():
 def _general_forced(rank, world, port, steps):
     os.environ["DTF_FORCE_GENERAL_SYNC"] = "1"
     return _general_gpu(rank, world, port, world, steps, -1)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Peer-mapped async engine: measured staleness, owner-resident Adam, no job-wide coupling in steady state
+# ------------------------------------------------------------------------------------------------------------------
+def _peer_async_v2(rank, world, port, shards, staleness, optimizer, steps, leaver=-1):
+    os.environ["DTF_PEER_ASYNC"] = "1"
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.async_peer import make_async_engine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=100, test_size=300, seed=rank)
+    st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, lr=0.5 if optimizer == "sgd" else 0.01,
+                         optimizer=optimizer)
+    st.initialize(seed=3)
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=rank), 100, [100], fused_update=False, gs_inc=0,
+                      post_update_accuracy=False)
+    eng = make_async_engine(prog, st, shards, staleness)
+    kind = type(eng).__name__
+    if rank == leaver:
+        eng.run(5, 5)
+        torch.cuda.synchronize()
+        return {"kind": kind, "left_after": 5}       # no finish(), no barrier: this worker is simply gone
+    eng.run(steps, 8)
+    torch.cuda.synchronize()
+    if leaver < 0:
+        dist.barrier()                               # everybody has pushed everything
+    else:
+        import time
+        time.sleep(1.0)                              # the leaver's five steps are long done
+    gs = eng.sync_params()
+    torch.cuda.synchronize()
+    recs = prog.read_log(0, steps)
+    smax, smean = eng.staleness_stats(0, steps)
+    pulls = eng.alog.cpu()[:steps]
+    everyone = eng.finish(timeout_s=3.0 if leaver >= 0 else 60.0)
+    out = {"kind": kind, "gs": gs, "first": recs[0].loss, "last": sum(r.loss for r in recs[-5:]) / 5.0,
+           "applied": eng.updates_applied_here, "params": st.params.cpu().numpy().copy(), "smax": smax, "smean": smean,
+           "gs_at_push": pulls[:, 0].tolist(), "everyone": everyone,
+           "m_norm": float(st.m.abs().sum().item()) if st.m is not None else 0.0, "adam_t": int(st.state[2].item())}
+    if leaver < 0:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def test_peer_async_staleness_is_measured_on_the_device():
+    """staleness 2: a worker pushes every step and pulls every third; the kernel logs how many updates of the OTHER
+    workers its replica had missed at each push."""
+    world, steps = 3, 30
+    res = run_ranks(_peer_async_v2, world, 1, 2, "sgd", steps)
+    assert all(r["kind"] == "PeerMappedAsyncEngine" for r in res)
+    assert all(r["gs"] == 1 + world * steps for r in res)           # global_step counts every worker's update
+    assert res[0]["applied"] == world * steps
+    for r in res[1:]:
+        assert (r["params"] == res[0]["params"]).all()              # after the last pull everybody holds the master
+    for r in res:
+        assert r["last"] < r["first"] - 0.1
+        assert 0 <= r["smean"] <= r["smax"] <= world * steps
+        assert all(b > a for a, b in zip(r["gs_at_push"], r["gs_at_push"][1:]))    # the counter only grows
+    assert max(r["smax"] for r in res) > 0                          # three workers do miss each other's updates
+
+
+def test_peer_async_adam_keeps_its_moments_with_the_owner():
+    world, steps = 2, 24
+    res = run_ranks(_peer_async_v2, world, 2, 0, "adam", steps)
+    assert all(r["kind"] == "PeerMappedAsyncEngine" for r in res)
+    assert all(r["gs"] == 1 + world * steps for r in res)
+    assert all(r["applied"] == world * steps for r in res)          # both own a slice; each slice saw every update
+    assert all(r["m_norm"] > 0 and r["adam_t"] == world * steps for r in res)     # slot variables came home at finish()
+    assert (res[0]["params"] == res[1]["params"]).all()
+    assert all(r["last"] < r["first"] - 0.05 for r in res)
+
+
+def test_peer_async_worker_that_leaves_does_not_block_the_others():
+    """Async workers only talk to the ps shards (device_filters, distributed.py:116-117): one of three workers runs
+    five steps and disappears; the other two finish their 30 steps, pull, and their finish() gives up waiting for
+    the missing worker after its time limit."""
+    world, steps, leaver = 3, 30, 2
+    res = run_ranks(_peer_async_v2, world, 1, 0, "sgd", steps, leaver, timeout=120)
+    assert res[leaver]["left_after"] == 5
+    assert res[0]["gs"] == res[1]["gs"] == 1 + 2 * steps + 5
+    assert res[0]["applied"] == 2 * steps + 5
+    assert res[0]["everyone"] is False and res[1]["everyone"] is False
+    assert (res[0]["params"] == res[1]["params"]).all()
