@@ -62,6 +62,11 @@ class Saver:
 
     def save(self, tensors: Dict[str, np.ndarray], directory: str, global_step: int) -> str:
         os.makedirs(directory, exist_ok=True)
+        if not self._kept:
+            # a restarted job continues the list of its predecessor: old bundles stay listed and are retired in turn
+            prev = read_checkpoint_state(directory)
+            if prev is not None:
+                self._kept = [p for p in prev["all_model_checkpoint_paths"] if os.path.exists(os.path.join(directory, p + ".index"))]
         name = f"{CKPT_BASENAME}-{int(global_step)}"
         prefix = os.path.join(directory, name)
         arrays = {}

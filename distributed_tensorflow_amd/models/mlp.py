@@ -83,6 +83,13 @@ class MLPProgram:
         in_dim = state.var(f"{self.names[0]}_w").shape[0]
         self.fused2 = (self.is_cuda and type(self)._supports_mlp2 and os.environ.get("DTF_FUSED_STEP", "1") != "0"
                        and ops.mlp2_eligible(in_dim, self.hidden, classes, batch))
+        if (self.is_cuda and type(self)._supports_mlp2 and not self.fused2 and os.environ.get("DTF_FUSED_STEP", "1") != "0"):
+            # a different code path, not just a different speed: say so once per program
+            import sys
+            sys.stderr.write(f"step program: {len(self.hidden)} hidden layer(s) of {self.hidden}, batch {batch}, {classes} classes "
+                             "is outside the two-launch step's range (one hidden layer <= 128 wide, batch <= 128, <= 16 "
+                             "classes): using the general three-launch sequence; multi-worker sync then aggregates through "
+                             "RCCL instead of the peer exchange inside the backward launch\n")
         # Per-step buffers rotate over P slots (slot of a step = local step % P).  P = 2: the tail of step s
         # writes the rows of step s+1 while step s is still being read.  The two-launch step also keeps the
         # gathered batch of step s-1 (its accuracy-only rows), hence P = 3.

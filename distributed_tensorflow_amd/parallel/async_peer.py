@@ -229,6 +229,25 @@ class PeerMappedAsyncEngine:
         return (torch.as_tensor(_DevicePtr(self._local + self.slice * 4, self.slice, "<f4"), device=self.device),
                 torch.as_tensor(_DevicePtr(self._local + self.slice * 8, self.slice, "<f4"), device=self.device))
 
+    def gather_moments(self):
+        """Full flat Adam moments read straight out of the owners' mapped regions (one-sided: no other rank takes
+        part, so the chief can checkpoint while everybody keeps training), or None for SGD."""
+        if not self.adam:
+            return None
+        n = self.state.layout.total
+        full_m = torch.empty(n, dtype=torch.float32, device=self.device)
+        full_v = torch.empty(n, dtype=torch.float32, device=self.device)
+        for s in range(self.S):
+            lo = s * self.slice
+            full_m[lo:lo + self.slice].copy_(torch.as_tensor(_DevicePtr(self._base[s] + self.slice * 4, self.slice, "<f4"),
+                                                             device=self.device))
+            full_v[lo:lo + self.slice].copy_(torch.as_tensor(_DevicePtr(self._base[s] + self.slice * 8, self.slice, "<f4"),
+                                                             device=self.device))
+        # the update count the bias correction uses is the owners' (shard 0 speaks for the job)
+        cnt = torch.as_tensor(_DevicePtr(self._base[0] + self._counter_off, COUNTER_BYTES // 4, "<i4"), device=self.device)
+        self.state.state[2] = int(cnt[1].item())
+        return full_m, full_v
+
     def _counter_view(self) -> torch.Tensor:
         return torch.as_tensor(_DevicePtr(self._local + self._counter_off, COUNTER_BYTES // 4, "<i4"), device=self.device)
 

@@ -14,17 +14,24 @@ slice each and are workers as well).  A worker step is
                        pull = recv(updated slice) from the owner   (side stream)
     continue with the next step; a pull may stay in flight for up to ``staleness`` steps
 
-and an owner runs a service thread that keeps one receive posted per remote worker on a
-dedicated two-rank communicator (so arrivals complete in any order), applies each arriving
-gradient to its slice with the fused SGD (or Adam: moments live with the owner, like the slot
-variables of a ps-resident optimizer) kernel, bumps ``global_step`` (owner of shard 0)
-and sends the fresh slice back.  ``backend='nccl'`` is RCCL over xGMI; ``gloo`` runs the
-same code on CPU.  Races between an owner's compute reading its slice and the service
-thread updating it are intended (lock-free updates, as the reference's use_locking=False).
+and an owner runs one service thread per remote worker.  Every request is announced by a
+two-word control message on a host-side (gloo) channel of the pair - the doorbell - and only
+then does the owner post the receive of the payload on the pair's data communicator: no
+receive kernel ever sits on the GPU waiting for a worker that has nothing to say (on RCCL a
+parked receive occupies a hardware queue and can stall the compute stream that shares it),
+and the request kind reaches the service thread without a device synchronisation.  The owner
+applies each arriving gradient to its slice with the fused SGD (or Adam: moments live with
+the owner, like the slot variables of a ps-resident optimizer) kernel, bumps ``global_step``
+(owner of shard 0) and sends the fresh slice back.  ``backend='nccl'`` is RCCL over xGMI;
+``gloo`` runs the same code on CPU.  Races between an owner's compute reading its slice and
+the service thread updating it are intended (lock-free updates, as the reference's
+use_locking=False).  Steps are launched one by one: every gradient has to pass through a
+host-issued send.  On one node the device-side engine (``async_peer.py``) is used instead.
 
-Wire format of one message (float32 buffer of ``shard_size + 2`` elements; the two extra
-slots carry int32 bit patterns): push = [grad..., kind, worker_local_step] with kind
-0 = gradient, 1 = worker finished, 2 = pull only; reply = [params..., global_step, 0].
+Control message: int64 [kind, worker_local_step] with kind 0 = gradient follows, 1 = worker
+finished, 2 = pull only, 3 = send me your Adam moments.  Payloads are float32 buffers of
+``shard_size + 2`` elements (the two extra slots of a reply carry int32 bit patterns:
+[params..., global_step, 0]).
 """
 from __future__ import annotations
 
@@ -39,17 +46,19 @@ import torch.distributed as dist
 from .. import ops
 from .sharded_state import ShardedState
 
-KIND_GRAD, KIND_DONE, KIND_PULL = 0, 1, 2
+KIND_GRAD, KIND_DONE, KIND_PULL, KIND_MOMENTS = 0, 1, 2, 3
 
 
 def build_pair_groups(world: int, num_shards: int) -> Dict[Tuple[int, int], object]:
-    """One two-rank group per (owner, worker) pair.  Collective: every rank must call this
-    with the same arguments, in the same order."""
+    """Per (owner, worker) pair a data group (the job's backend) under key ``(o, w)`` and a host-side control
+    group (gloo) under ``(o, w, "ctl")``.  Collective: every rank must call this with the same arguments, in the
+    same order."""
     groups = {}
     for o in range(num_shards):
         for w in range(world):
             if w != o:
                 groups[(o, w)] = dist.new_group([o, w])
+                groups[(o, w, "ctl")] = dist.new_group([o, w], backend="gloo")
     return groups
 
 
@@ -145,15 +154,23 @@ class AsyncParameterServerEngine:
         st = self.state
         lo, hi = self._shard_range(self.rank)
         master = st.params[lo:hi]
-        group = self.groups[(self.rank, w)]
+        group, ctl_group = self.groups[(self.rank, w)], self.groups[(self.rank, w, "ctl")]
         msg, out = self._in[w], self._out[w]
+        ctl = torch.zeros(2, dtype=torch.int64)
         while True:
-            dist.recv(msg, src=w, group=group)
-            kind = int(self._ints(msg)[0].item())
+            dist.recv(ctl, src=w, group=ctl_group)      # the doorbell: blocks on the host, nothing is parked on the GPU
+            kind = int(ctl[0])
             if kind == KIND_DONE:
                 return
+            if kind == KIND_MOMENTS:
+                for t in (self._m, self._v):
+                    out[:self.slice].copy_(t) if t is not None else out[:self.slice].zero_()
+                    self._ints(out)[0] = self._adam_t
+                    dist.send(out, dst=w, group=group)
+                continue
             gs = None
             if kind == KIND_GRAD:
+                dist.recv(msg, src=w, group=group)       # posted only now that the worker has announced its push
                 # lock-free apply on the owned slice (ApplyGradientDescent on the ps, use_locking=False)
                 self._apply(master, msg[:self.slice])
                 if self.rank == 0:
@@ -173,7 +190,8 @@ class AsyncParameterServerEngine:
         slot, works = self._pending.popleft()
         st = self.state
         for s, send_w, recv_w in works:
-            send_w.wait()
+            if send_w is not None:
+                send_w.wait()
             recv_w.wait()
             lo, hi = self._shard_range(s)
             buf = self._pull_buf[s][slot]
@@ -199,18 +217,19 @@ class AsyncParameterServerEngine:
                     else:
                         with self._gs_lock:
                             self._applied += 1
+                elif s == 0:
+                    with self._gs_lock:         # a pull by the owner of shard 0: the counter its service threads advanced
+                        st.state[0] = self._gs
                 continue
-            buf = self._push_buf[s][slot]
-            if kind == KIND_GRAD:
-                buf[:self.slice].copy_(st.grads[lo:hi])
-            ints = self._ints(buf)
-            ints[0] = kind
-            ints[1] = self.updates_pushed
             g = self.groups[(s, self.rank)]
-            send_w = dist.isend(buf, dst=s, group=g)
+            dist.send(torch.tensor([kind, self.updates_pushed], dtype=torch.int64), dst=s, group=self.groups[(s, self.rank, "ctl")])
             if kind == KIND_DONE:
-                send_w.wait()
                 continue
+            send_w = None
+            if kind == KIND_GRAD:
+                buf = self._push_buf[s][slot]
+                buf[:self.slice].copy_(st.grads[lo:hi])
+                send_w = dist.isend(buf, dst=s, group=g)
             recv_w = dist.irecv(self._pull_buf[s][slot], src=s, group=g)
             works.append((s, send_w, recv_w))
         if works:
@@ -242,26 +261,73 @@ class AsyncParameterServerEngine:
         Returns the freshest global_step this worker knows."""
         while self._pending:
             self._complete_oldest()
-        if self._pull_buf:
-            self._exchange(KIND_PULL)
-            while self._pending:
-                self._complete_oldest()
+        self._exchange(KIND_PULL)
+        while self._pending:
+            self._complete_oldest()
         self.last_global_step = self.state.global_step()
         return self.last_global_step
 
-    def finish(self) -> None:
-        """This worker is done: tell the owners, then (owners) keep serving until everyone is done."""
+    def publish_state(self) -> None:
+        """After the chief has initialised or restored the variables: the owners take their counters (and Adam
+        moments) from the local state instead of starting from scratch."""
+        st = self.state
+        with self._gs_lock:
+            self._gs = st.global_step()
+            self._adam_t = int(st.state[2].item())
+        lo, hi = self._shard_range(self.rank) if self.is_owner else (0, 0)
+        if self._m is not None and st.m is not None and (lo, hi) == tuple(st.shard):
+            self._m.copy_(st.m)
+            self._v.copy_(st.v)
+
+    def gather_moments(self):
+        """Full flat Adam moments: this rank's own slice directly, the other owners' through a request on the pair
+        channels (the requester is the only other party involved), or None for SGD."""
+        st = self.state
+        if st.optimizer != "adam":
+            return None
+        while self._pending:
+            self._complete_oldest()
+        n = st.layout.total
+        full = [torch.zeros(n, dtype=torch.float32, device=self.device) for _ in range(2)]
+        scratch = torch.zeros(self.slice + 2, dtype=torch.float32, device=self.device)
+        for s in range(self.S):
+            lo, hi = self._shard_range(s)
+            if s == self.rank:
+                full[0][lo:hi].copy_(self._m)
+                full[1][lo:hi].copy_(self._v)
+                st.state[2] = self._adam_t
+                continue
+            dist.send(torch.tensor([KIND_MOMENTS, 0], dtype=torch.int64), dst=s, group=self.groups[(s, self.rank, "ctl")])
+            for k in range(2):
+                dist.recv(scratch, src=s, group=self.groups[(s, self.rank)])
+                full[k][lo:hi].copy_(scratch[:self.slice])
+            if s == 0:
+                st.state[2:3].copy_(self._ints(scratch)[0:1])
+        return full[0], full[1]
+
+    def finish(self, timeout_s: float = 120.0) -> bool:
+        """This worker is done: tell the owners, then (owners) keep serving until everyone is done - or until the time
+        limit: a worker that died never says so, and must not keep the others from leaving.  Returns whether every
+        service thread saw its worker finish."""
+        import time
         while self._pending:
             self._complete_oldest()
         if self.world > 1:
             self._exchange(KIND_DONE)
+        deadline = time.time() + timeout_s
         for t in self._threads:
-            t.join()
+            t.join(max(0.0, deadline - time.time()))
+        everyone = not any(t.is_alive() for t in self._threads)      # daemon threads: a stuck one ends with the process
         self._check_service()
         if self.device.type == "cuda":
             torch.cuda.synchronize()
         if self.rank == 0:
             self.state.state[0] = self._gs
+        if self._m is not None and self.state.m is not None and self._shard_range(self.rank) == tuple(self.state.shard):
+            self.state.m.copy_(self._m)
+            self.state.v.copy_(self._v)
+            self.state.state[2] = self._adam_t
+        return everyone
 
     @property
     def updates_applied_here(self) -> int:

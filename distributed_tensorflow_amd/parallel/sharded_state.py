@@ -23,6 +23,7 @@ import torch
 from .. import ops
 
 ALIGN = 64  # elements; every variable starts on a 256-byte boundary of the flat buffer
+LOCAL_STEP_KEY = "dtf/local_step"   # checkpoint entry beyond the reference's variables: the saving worker's local step
 
 
 @dataclass
@@ -167,10 +168,16 @@ class ShardedState:
 
     def load_values(self, values: Dict[str, torch.Tensor], global_step: Optional[int] = None) -> None:
         """Inject explicit values (parity tests, checkpoint restore)."""
+        names = set(self.names())
         for name, val in values.items():
             if name == "global_step":
                 global_step = int(val)
                 continue
+            if name == LOCAL_STEP_KEY:
+                self.state[1] = int(val)
+                continue
+            if name not in names:
+                continue                    # optimizer slots (load_moments) and whatever else the bundle holds
             dst = self.var(name)
             val = torch.as_tensor(val, dtype=torch.float32)
             if tuple(val.shape) != tuple(dst.shape):
@@ -181,12 +188,71 @@ class ShardedState:
         self.initialized = True
         self.values_version += 1
 
-    def named_tensors(self) -> Dict[str, torch.Tensor]:
-        """Everything the reference's default Saver would write: global_step + trainable variables."""
+    def named_tensors(self, moments: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """Everything the reference's default Saver would write: global_step + trainable variables (distributed.py:
+        65-73, :110-111), plus this worker's local step (``dtf/local_step``: where its data pipeline stands, so that a
+        restored run continues the same trajectory).  With Adam and ``moments`` = the full flat (m, v) buffers gathered
+        from their owners, also the optimizer's slot variables under the names a TF ``AdamOptimizer`` gives them:
+        ``<var>/Adam``, ``<var>/Adam_1``, ``beta1_power``, ``beta2_power``."""
         out = {"global_step": self.state[0:1].cpu().reshape(())}
         for v in self.layout.variables:
             out[v.name] = self.var(v.name).detach().cpu().clone()
+        out[LOCAL_STEP_KEY] = self.state[1:2].cpu().reshape(())
+        if self.optimizer == "adam" and moments is not None:
+            full_m, full_v = moments
+            if full_m.numel() != self.layout.total or full_v.numel() != self.layout.total:
+                raise ValueError("moments must be the full flat buffers (gather them from their owners first)")
+            for v in self.layout.variables:
+                out[f"{v.name}/Adam"] = self._view(full_m, v.name).detach().cpu().clone()
+                out[f"{v.name}/Adam_1"] = self._view(full_v, v.name).detach().cpu().clone()
+            t = int(self.state[2].item())
+            # TF keeps beta^(t+1) after t updates (the accumulators start at beta and are multiplied once per update)
+            out["beta1_power"] = torch.tensor(self.beta1 ** (t + 1), dtype=torch.float32)
+            out["beta2_power"] = torch.tensor(self.beta2 ** (t + 1), dtype=torch.float32)
         return out
+
+    def gather_moments(self, coll=None) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+        """Full flat Adam moments assembled from the ranks' slices (X10, the checkpoint gather).  Collective when the
+        state is sharded over several ranks: every rank calls it with the job's ``Collectives``."""
+        if self.optimizer != "adam":
+            return None
+        if self.world_size == 1:
+            return self.m, self.v
+        if coll is None:
+            raise ValueError("gathering the moments of a sharded state needs the job's collectives")
+        full_m = torch.empty(self.layout.total, dtype=torch.float32, device=self.device)
+        full_v = torch.empty_like(full_m)
+        coll.all_gather(full_m, self.m)
+        coll.all_gather(full_v, self.v)
+        return full_m, full_v
+
+    def load_moments(self, values: Dict[str, torch.Tensor]) -> bool:
+        """Restore Adam's slot variables from checkpoint tensors (every rank keeps the slice it owns).  Returns False
+        (state untouched: moments start at zero) when the checkpoint holds none."""
+        got = self.moments_from_values(values)
+        if got is None:
+            return False
+        full_m, full_v, t = got
+        lo, hi = self.shard
+        self.m.copy_(full_m[lo:hi])
+        self.v.copy_(full_v[lo:hi])
+        self.state[2] = t
+        return True
+
+    def moments_from_values(self, values: Dict[str, torch.Tensor]):
+        """(full flat m, full flat v, updates applied) on the host from checkpoint tensors, or None without Adam slots."""
+        if self.optimizer != "adam" or "beta1_power" not in values:
+            return None
+        import math
+        full_m = torch.zeros(self.layout.total, dtype=torch.float32)
+        full_v = torch.zeros(self.layout.total, dtype=torch.float32)
+        for v in self.layout.variables:
+            for key, full in ((f"{v.name}/Adam", full_m), (f"{v.name}/Adam_1", full_v)):
+                if key not in values:
+                    raise ValueError(f"checkpoint has beta1_power but no {key}")
+                self._view(full, v.name).copy_(torch.as_tensor(values[key], dtype=torch.float32))
+        t = int(round(math.log(float(values["beta1_power"])) / math.log(self.beta1))) - 1
+        return full_m, full_v, max(0, t)
 
     # ---- optimizer on the owned slice
     def apply_shard(self, grad_shard: Optional[torch.Tensor] = None, grad_scale: float = 1.0) -> None:

@@ -7,6 +7,11 @@
   and then receives the chief's values.
 * The chief saves ``model.ckpt-<global_step>`` every ``save_model_secs`` (600 s, the Supervisor
   default) and once more at ``stop()``; it also reports ``global_step/sec`` every 120 s.
+* With Adam the optimizer's slot variables are saved and restored too (a default TF Saver covers
+  them: ``<var>/Adam``, ``<var>/Adam_1``, ``beta1_power``, ``beta2_power``).  They live with the
+  owners of the parameter slices: in sync mode every worker joins the gather (the chief's decision
+  to save travels in a one-word broadcast per call), in async mode the chief reads the owners'
+  mapped regions by itself.
 
 Checkpoints are taken by the training loop between hipGraph launches (``maybe_checkpoint``),
 not by a timer thread racing the update kernels: the snapshot is always a consistent parameter
@@ -51,6 +56,26 @@ class Supervisor:
         self.waited_polls = 0
         self._events = None
         self._tb = None                  # TensorBoard event file (events.out.tfevents.*), chief only
+        self.engine = None               # set by the training script: async engines hand out the owner-resident moments
+        self.restored_values: Optional[Dict] = None
+
+    # ------------------------------------------------------------------ who takes part in a save
+    def _collective_save(self) -> bool:
+        """Sync mode, Adam, several ranks: the moments are sharded, every rank contributes its slice."""
+        st = self.state
+        return (getattr(st, "optimizer", "sgd") == "adam" and self.group_size > 1 and dist.is_initialized()
+                and not hasattr(self.engine, "gather_moments"))
+
+    def _moments(self):
+        st = self.state
+        if getattr(st, "optimizer", "sgd") != "adam":
+            return None
+        if self.engine is not None and hasattr(self.engine, "gather_moments"):
+            return self.engine.gather_moments()              # async: one-sided, chief only
+        if self.group_size > 1 and dist.is_initialized():
+            from ..parallel.comm import Collectives
+            return st.gather_moments(Collectives())
+        return st.gather_moments()
 
     # ------------------------------------------------------------------ session bring-up
     def prepare_or_wait_for_session(self) -> None:
@@ -62,6 +87,7 @@ class Supervisor:
                 st.load_values({k: torch.from_numpy(v) for k, v in values.items() if k != "global_step"},
                                global_step=int(values["global_step"]))
                 self.restored_from = ckpt
+                self.restored_values = values
             else:
                 self.init_fn()
             if self.store is not None:
@@ -80,22 +106,67 @@ class Supervisor:
             coll.broadcast(st.state, 0)
             st.values_version += 1
             st.initialized = True
+            if getattr(st, "optimizer", "sgd") == "adam":
+                # the slot variables: the chief broadcasts the full buffers, every rank keeps the slice it owns
+                have = torch.tensor([1 if (self.is_chief and self.restored_values is not None
+                                           and "beta1_power" in self.restored_values) else 0], dtype=torch.int32,
+                                    device=st.device if coll.backend == "nccl" else "cpu")
+                coll.broadcast(have, 0)
+                if int(have.item()):
+                    self._broadcast_moments(coll)
+        elif self.is_chief and self.restored_values is not None and getattr(st, "optimizer", "sgd") == "adam":
+            st.load_moments({k: torch.from_numpy(v) for k, v in self.restored_values.items()})
         self._last_save = time.time()
         self._last_rate_time = time.time()
         self._last_rate_step = None
 
+    def _broadcast_moments(self, coll) -> None:
+        st = self.state
+        n = st.layout.total
+        lo, hi = st.shard
+        full = torch.zeros((2, n), dtype=torch.float32, device=st.device)
+        t = torch.zeros(1, dtype=torch.int32, device=st.device)
+        if self.is_chief:
+            full_m, full_v, steps = st.moments_from_values({k: torch.from_numpy(v) for k, v in self.restored_values.items()})
+            full[0].copy_(full_m)
+            full[1].copy_(full_v)
+            t[0] = steps
+        coll.broadcast(full, 0)
+        coll.broadcast(t, 0)
+        st.m.copy_(full[0, lo:hi])
+        st.v.copy_(full[1, lo:hi])
+        st.state[2] = int(t.item())
+
     # ------------------------------------------------------------------ services driven by the training loop
     def save(self, global_step: Optional[int] = None) -> Optional[str]:
+        """Write ``model.ckpt-<global_step>``.  Chief only - except that with sharded Adam moments (sync mode, several
+        ranks) every rank must call it: the gather of the slot variables is a collective."""
+        collective = self._collective_save()
+        if not self.is_chief and not collective:
+            return None
+        moments = self._moments()
         if not self.is_chief:
             return None
-        tensors = self.state.named_tensors()
+        tensors = self.state.named_tensors(moments)
         gs = int(tensors["global_step"]) if global_step is None else global_step
         path = self.saver.save(tensors, self.logdir, gs)
         self._last_save = time.time()
         return path
 
     def maybe_checkpoint(self) -> Optional[str]:
-        if not self.is_chief or not self.save_model_secs:
+        if not self.save_model_secs:
+            return None
+        if self._collective_save():
+            # every rank is here once per launch; the chief's clock decides for all
+            due = torch.tensor([1 if (self.is_chief and time.time() - self._last_save >= self.save_model_secs) else 0],
+                               dtype=torch.int32)
+            from ..parallel.comm import Collectives
+            coll = Collectives()
+            if coll.backend == "nccl":
+                due = due.to(self.state.device)
+            coll.broadcast(due, 0)
+            return self.save() if int(due.item()) else None
+        if not self.is_chief:
             return None
         if time.time() - self._last_save >= self.save_model_secs:
             return self.save()
@@ -133,7 +204,7 @@ class Supervisor:
         return rate
 
     def stop(self, save: bool = True) -> None:
-        if save and self.is_chief and self.save_model_secs:
+        if save and self.save_model_secs and (self.is_chief or self._collective_save()):
             self.save()
         if self._events is not None:
             self._events.close()

@@ -255,6 +255,7 @@ def main(unused_argv=None) -> int:
                     group_size=num_workers,                                                # :108-111
                     examples_per_global_step=FLAGS.batch_size * ((FLAGS.replicas_to_aggregate or num_workers)
                                                                  if FLAGS.sync_replicas else 1))
+    sv.engine = engine
     if is_chief:
         print('Worker %d: Initailizing session...' % FLAGS.task_index)                     # :122
     else:

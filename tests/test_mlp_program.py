@@ -10,6 +10,22 @@ from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
 from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
 
 
+@pytest.fixture
+def one_rank_rccl_group():
+    """A one-rank RCCL process group for the tests that exercise the collective code paths on a single GPU; torn
+    down afterwards so that it neither leaks into later tests nor outlives the interpreter."""
+    import torch.distributed as dist
+    from dist_utils import free_port
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    yield
+    if created and dist.is_initialized():
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
 def _make(device, hidden=(100,), batch=100, lr=0.01, post=True, loss_mode=ops.LOSS_REFERENCE, n_train=1000, seed=5,
           fused=True, use_graphs=None):
     ds = mnist.synthetic_data_sets(train_size=n_train, validation_size=200, test_size=300, seed=seed)
@@ -138,15 +154,12 @@ def test_gpu_trajectory_matches_cpu(hidden, post, graphs):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("collective,optimizer", [("all_reduce", "sgd"), ("reduce_scatter", "sgd"), ("reduce_scatter", "adam")])
-def test_gpu_rccl_collectives_in_captured_step(collective, optimizer):
+def test_gpu_rccl_collectives_in_captured_step(collective, optimizer, one_rank_rccl_group):
     """One-rank RCCL group: the reduce-scatter / all-gather / all-reduce calls of the sync engine,
     captured in the step hipGraph, must leave the trajectory identical to the fused local update."""
     import torch.distributed as dist
     from dist_utils import free_port
     from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
-                                device_id=torch.device("cuda", 0))
     steps = 24
     ds = mnist.synthetic_data_sets(train_size=1000, validation_size=200, test_size=300, seed=5)
 
@@ -188,15 +201,12 @@ def test_gpu_cli_single_worker_runs_hip_path(capsys):
 
 
 @pytest.mark.gpu
-def test_gpu_native_rccl_update_entry_is_used_and_matches_torch_collectives(monkeypatch):
+def test_gpu_native_rccl_update_entry_is_used_and_matches_torch_collectives(monkeypatch, one_rank_rccl_group):
     """The engine's GPU fast path must run through the native RCCL communicator (one-rank group here);
     with DTF_NATIVE_COMM=0 the torch.distributed path must give the same trajectory."""
     import torch.distributed as dist
     from dist_utils import free_port
     from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
-                                device_id=torch.device("cuda", 0))
     ds = mnist.synthetic_data_sets(train_size=1000, validation_size=200, test_size=300, seed=5)
 
     def make(native, coll, optimizer):
@@ -260,21 +270,19 @@ def test_gpu_two_launch_step_matches_three_launch_step(monkeypatch, hidden, batc
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", ["1", "0"])
-def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch, fused):
+@pytest.mark.parametrize("fused", ["1", "0", "sharded"])
+def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch, fused, one_rank_rccl_group):
     """DTF_P2P_ALLREDUCE=1 on a one-rank group: gradients go through the exported slot buffers and the one-shot
     update kernel (captured in the step graph); the trajectory must equal the fused local update."""
     import torch.distributed as dist
     from dist_utils import free_port
     from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
-                                device_id=torch.device("cuda", 0))
     ds = mnist.synthetic_data_sets(train_size=1000, validation_size=200, test_size=300, seed=5)
 
     def make(p2p):
         monkeypatch.setenv("DTF_P2P_ALLREDUCE", "1" if p2p else "0")
-        monkeypatch.setenv("DTF_P2P_FUSED", fused)
+        monkeypatch.setenv("DTF_P2P_FUSED", "1" if fused == "sharded" else fused)
+        monkeypatch.setenv("DTF_P2P_MODE", "sharded" if fused == "sharded" else "replicated")
         st = build_mlp_state(784, [100], 10, "cuda", lr=0.3)
         st.initialize(seed=11)
         prog = MLPProgram(st, DeviceDataset(ds.train, "cuda", shuffle_seed=5), 100, [100], fused_update=not p2p)
@@ -286,7 +294,7 @@ def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch, fused):
     st_p, prog_p, eng_p = make(True)
     st_f, prog_f, eng_f = make(False)
     assert eng_p.p2p is not None and prog_p.after_compute is None and eng_f.p2p is None
-    assert eng_p.p2p_fused == (fused == "1")
+    assert eng_p.p2p_fused == (fused != "0") and eng_p.p2p_mode == ("sharded" if fused == "sharded" else "replicated")
     for a, b in zip(prog_p.read_log(0, 30), prog_f.read_log(0, 30)):
         assert abs(a.loss - b.loss) < 1e-5 and a.global_step == b.global_step
     torch.testing.assert_close(st_p.params, st_f.params, rtol=1e-5, atol=1e-6)

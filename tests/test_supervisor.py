@@ -30,7 +30,8 @@ def test_chief_initializes_then_restores_from_checkpoint(tmp_path):
     assert path.endswith("model.ckpt-4321")
     # the file is a TF-Saver-layout bundle readable by the independent Python reader
     got = pyformat.read_bundle(path)
-    assert sorted(got) == ["global_step", "hid_b", "hid_w", "sm_b", "sm_w"]
+    # the reference's five variables, plus the saving worker's local step (where its data pipeline stands)
+    assert sorted(got) == ["dtf/local_step", "global_step", "hid_b", "hid_w", "sm_b", "sm_w"]
     assert int(got["global_step"]) == 4321 and got["global_step"].dtype.name == "int32" and got["hid_w"].shape == (784, 100)
     # a new chief pointed at the same directory resumes instead of re-initialising
     st2 = _state()
