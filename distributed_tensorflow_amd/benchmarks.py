@@ -278,6 +278,7 @@ def _prepare_graphs(prog, args, graph_steps, device, steps_per_update: int = 1) 
 def bench_resnet50_sync(args, rank, world, device):
     from .models.resnet import TorchModuleProgram, resnet50
     from .ops.batchnorm import calls as bn_calls
+    from .ops.classifier import calls as head_calls
     batch = args.batch_size or 256
     optimizer = args.optimizer or "adam"
     dtype_name = args.dtype or "bf16"
@@ -312,6 +313,9 @@ def bench_resnet50_sync(args, rank, world, device):
                    "parallelism": f"dp{world} sync_replicas, optimizer state sharded over {world} GPU(s)",
                    "optimizer": optimizer, "mode": "sync", "collective": engine.collective if world > 1 else "none",
                    "params": prog.state.layout.used, "convolutions": "MIOpen (library)",
+                   "classifier": ("own kernels (MFMA GEMM + fused softmax cross-entropy)"
+                                  if head_calls["kernel"] and not head_calls["operators"]
+                                  else "PyTorch operators" if not head_calls["kernel"] else "mixed"),
                    "batch_norm": ("fused kernels (batchnorm.hip)" if bn_calls["kernel"] and not bn_calls["operators"]
                                   else "PyTorch operators" if not bn_calls["kernel"] else "mixed")},
         "final_loss": last.loss,

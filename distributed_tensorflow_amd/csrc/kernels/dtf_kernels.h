@@ -95,6 +95,24 @@ struct DtfHeadArgs {
   int ld_bf, ld_bf_t;       //     bf16 products, written here instead of by a cast pass over the fp32 dz1 (which may be null)
 };
 
+// Fused softmax cross-entropy over [B, C] logits for any C (softmax_xent.hip): loss, gradient, accuracy count.
+struct DtfXentArgs {
+  const float* logits;        // [B, ld_logits]
+  const float* labels_f;      // one-hot / soft labels [B, ld_labels], or null
+  const long long* labels_i;  // class indices [B], or null (exactly one of the two label forms)
+  float* dlogits;             // optional gradient [B, ld_dlogits] fp32
+  void* dlogits_bf;           // optional gradient [B, ld_dlogits_bf] bf16 (operand of the backward products)
+  float* loss_rows;           // optional per-row loss [B]
+  float* loss_part;           // optional [ceil(B/4)] per-workgroup loss sums
+  int* correct_part;          // optional [ceil(B/4)] per-workgroup counts of argmax(logits) == argmax(labels)
+  int B, C;
+  int ld_logits, ld_labels, ld_dlogits, ld_dlogits_bf;
+  int loss_mode;              // 0: reference (softmax applied twice), 1: standard cross-entropy on the logits
+  float grad_scale;           // usually 1 / B (mean loss)
+};
+DTF_EXPORT int dtf_softmax_xent(const DtfXentArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_softmax_xent_blocks(int B);
+
 // Two-launch training step of the one-hidden-layer network (mlp2_fused.hip): launch 1 = hidden layer
 // + per-column-tile partial logits, launch 2 = loss/accuracy records, softmax gradient, both weight
 // gradients (optionally the SGD update), the step tail and the gather of the next batch.  One struct

@@ -26,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct
+from ..ops.classifier import linear_xent
 from ..parallel.sharded_state import ShardedState, VariableSpec
 from .mlp import StepRecord
 
@@ -75,12 +76,15 @@ class ResNet(nn.Module):
         layers += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
-    def forward(self, x):
+    def forward(self, x, features_only: bool = False):
+        """Logits, or with ``features_only`` the pooled features in front of ``fc``: the training step then runs
+        classifier and loss as one node on the framework's GEMM and softmax cross-entropy kernels
+        (``ops/classifier.linear_xent`` with ``self.fc``'s parameters)."""
         x = self.bn1(self.conv1(x))
         x = F.max_pool2d(x, 3, stride=2, padding=1)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
-        return self.fc(x)
+        return x if features_only else self.fc(x)
 
 
 def resnet50(num_classes=1000, width=64, layers=(3, 4, 6, 3)) -> ResNet:
@@ -121,6 +125,8 @@ class TorchModuleProgram:
         self.gs_inc = gs_inc
         self.fused = False
         self.post = False
+        # classifier and loss on the framework's kernels where the module exposes its features (DTF_FUSED_HEAD=0: operators)
+        self.fused_head = isinstance(self.module, ResNet) and os.environ.get("DTF_FUSED_HEAD", "1") != "0"
         # DTF_MODULE_GRAPH=1, one rank on a GPU: the whole step (forward, backward, optimizer) is captured into a
         # hipGraph after three eager steps and replayed; the host then only copies the next batch into the graph's
         # input buffers.  Opt-in: the ResNet-50 step is bound by the GPU (31.14 ms replayed, 31.15 ms eager).
@@ -188,12 +194,21 @@ class TorchModuleProgram:
     def _step_body(self, x, y) -> None:
         """The device work of one step; touches no host state, so it can be captured and replayed."""
         self.state.grads.zero_()
-        with torch.autocast(self.device.type, dtype=self.autocast, enabled=self.autocast is not None):
-            logits = self.module(x)
-        loss = F.cross_entropy(logits.float(), y)
-        loss.backward()
-        self._last[0:1].copy_(loss.detach().reshape(1))
-        self._last[1:2].copy_((logits.argmax(1) == y).sum().float().reshape(1))
+        if self.fused_head:
+            # classifier + loss + accuracy count: one autograd node on the framework's own kernels
+            with torch.autocast(self.device.type, dtype=self.autocast, enabled=self.autocast is not None):
+                feat = self.module(x, features_only=True)
+            loss, hits, _ = linear_xent(feat, self.module.fc.weight, self.module.fc.bias, y)
+            loss.backward()
+            self._last[0:1].copy_(loss.detach().reshape(1))
+            self._last[1:2].copy_(hits.reshape(1))
+        else:
+            with torch.autocast(self.device.type, dtype=self.autocast, enabled=self.autocast is not None):
+                logits = self.module(x)
+            loss = F.cross_entropy(logits.float(), y)
+            loss.backward()
+            self._last[0:1].copy_(loss.detach().reshape(1))
+            self._last[1:2].copy_((logits.argmax(1) == y).sum().float().reshape(1))
         self._last_gs.copy_(self.state.state[0:1])
         if self.after_compute is not None:
             self.after_compute()

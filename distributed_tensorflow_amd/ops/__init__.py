@@ -274,6 +274,82 @@ def head(hact, w2, b2, labels, m_total, m_train, loss_mode=LOSS_REFERENCE, rows=
     return args
 
 
+class XentResult:
+    """Outputs of :func:`softmax_xent`: per-workgroup partial loss sums and hit counts (device tensors, folded without
+    a host synchronisation by ``loss_sum`` / ``correct``), optional per-row losses and gradients."""
+
+    def __init__(self, loss_part, correct_part, loss_rows, dlogits, dlogits_bf, args=None):
+        self.loss_part, self.correct_part, self.loss_rows = loss_part, correct_part, loss_rows
+        self.dlogits, self.dlogits_bf, self.args = dlogits, dlogits_bf, args
+
+    @property
+    def loss_sum(self) -> torch.Tensor:
+        return self.loss_part.sum()
+
+    @property
+    def correct(self) -> torch.Tensor:
+        return self.correct_part.sum()
+
+
+def softmax_xent(logits, labels, loss_mode=LOSS_STANDARD, grad_scale=None, want_grad=True, dlogits=None, dlogits_bf=None,
+                 loss_rows=None, loss_part=None, correct_part=None) -> XentResult:
+    """Fused softmax cross-entropy for ANY class count (K3-K5 of the reference graph beyond the 16-class head
+    kernel; ``csrc/kernels/softmax_xent.hip``): loss, gradient wrt the logits (scaled by ``grad_scale``, default
+    ``1/B``) and the argmax hit count in one pass.  ``labels``: float ``[B, C]`` (one-hot / soft) or int64 ``[B]``
+    class indices.  ``loss_mode``: ``LOSS_STANDARD`` or ``LOSS_REFERENCE`` (softmax applied twice, distributed.py:81+86).
+    ``dlogits_bf``: additionally (or only) the gradient as bf16, the operand of bf16 backward products."""
+    if logits.dim() != 2 or logits.dtype != torch.float32:
+        raise ValueError("softmax_xent: logits must be float32 [B, C]")
+    b, c = logits.shape
+    if labels.dim() == 2:
+        if tuple(labels.shape) != (b, c) or labels.dtype != torch.float32:
+            raise ValueError("softmax_xent: label rows must be float32 [B, C]")
+    elif labels.dim() != 1 or labels.numel() != b or labels.dtype != torch.int64:
+        raise ValueError("softmax_xent: class indices must be int64 [B]")
+    scale = (1.0 / b) if grad_scale is None else float(grad_scale)
+    dev = logits.device
+    if not logits.is_cuda:
+        r = reference.softmax_xent(logits, labels, loss_mode, scale)
+        lp = torch.zeros(1, dtype=torch.float32) if loss_part is None else loss_part.zero_()
+        cp = torch.zeros(1, dtype=torch.int32) if correct_part is None else correct_part.zero_()
+        lp[0], cp[0] = r["loss_rows"].sum(), r["correct"]
+        if loss_rows is not None:
+            loss_rows.copy_(r["loss_rows"])
+        if want_grad and dlogits is None and dlogits_bf is None:
+            dlogits = torch.empty_like(logits)
+        if dlogits is not None:
+            dlogits.copy_(r["dlogits"])
+        if dlogits_bf is not None:
+            dlogits_bf.copy_(r["dlogits"])
+        return XentResult(lp, cp, r["loss_rows"] if loss_rows is None else loss_rows, dlogits, dlogits_bf)
+    lib = _lib.kernels()
+    nblk = lib.dtf_softmax_xent_blocks(b)
+    if loss_part is None:
+        loss_part = torch.empty(nblk, dtype=torch.float32, device=dev)
+    if correct_part is None:
+        correct_part = torch.empty(nblk, dtype=torch.int32, device=dev)
+    if loss_part.numel() < nblk or correct_part.numel() < nblk:
+        raise ValueError(f"softmax_xent: partial buffers need {nblk} entries")
+    if want_grad and dlogits is None and dlogits_bf is None:
+        dlogits = torch.empty_like(logits)
+    for name, t, dt in (("dlogits", dlogits, torch.float32), ("dlogits_bf", dlogits_bf, torch.bfloat16)):
+        if t is not None and (t.dtype != dt or t.shape[0] < b or t.shape[1] != c or t.stride(1) != 1):
+            raise ValueError(f"softmax_xent: {name} must be {dt} [>=B, C], row-major")
+    if logits.stride(1) != 1 or (labels.dim() == 2 and labels.stride(1) != 1):
+        raise ValueError("softmax_xent: operands must be row-major")
+    _same_device(logits, labels, dlogits, dlogits_bf, loss_rows, loss_part, correct_part)
+    args = _lib.XentArgs(logits=logits.data_ptr(), labels_f=labels.data_ptr() if labels.dim() == 2 else None,
+                         labels_i=labels.data_ptr() if labels.dim() == 1 else None, dlogits=_lib.ptr(dlogits),
+                         dlogits_bf=_lib.ptr(dlogits_bf), loss_rows=_lib.ptr(loss_rows), loss_part=loss_part.data_ptr(),
+                         correct_part=correct_part.data_ptr(), B=b, C=c, ld_logits=logits.stride(0),
+                         ld_labels=labels.stride(0) if labels.dim() == 2 else 0,
+                         ld_dlogits=0 if dlogits is None else dlogits.stride(0),
+                         ld_dlogits_bf=0 if dlogits_bf is None else dlogits_bf.stride(0), loss_mode=int(loss_mode),
+                         grad_scale=scale)
+    _lib.check(lib.dtf_softmax_xent(C.byref(args), _lib.stream_handle()), "softmax_xent")
+    return XentResult(loss_part[:nblk], correct_part[:nblk], loss_rows, dlogits, dlogits_bf, args)
+
+
 def mlp2_eligible(in_dim, hidden, classes, batch) -> bool:
     """Shapes the two-launch step of ``csrc/kernels/mlp2_fused.hip`` covers (the reference network does)."""
     return len(hidden) == 1 and hidden[0] <= 128 and classes <= 16 and batch <= 128 and in_dim % 4 == 0

@@ -89,6 +89,14 @@ class OptRangesArgs(C.Structure):
                 ("gscale", C.c_float), ("pad_", C.c_int)]
 
 
+class XentArgs(C.Structure):
+    """Mirror of ``DtfXentArgs`` (softmax_xent.hip)."""
+    _fields_ = [("logits", C.c_void_p), ("labels_f", C.c_void_p), ("labels_i", C.c_void_p), ("dlogits", C.c_void_p),
+                ("dlogits_bf", C.c_void_p), ("loss_rows", C.c_void_p), ("loss_part", C.c_void_p), ("correct_part", C.c_void_p),
+                ("B", C.c_int), ("C", C.c_int), ("ld_logits", C.c_int), ("ld_labels", C.c_int), ("ld_dlogits", C.c_int),
+                ("ld_dlogits_bf", C.c_int), ("loss_mode", C.c_int), ("grad_scale", C.c_float)]
+
+
 class Mlp2Peer(C.Structure):
     """Mirror of ``DtfMlp2Peer``: peers' gradient slots and arrival flags for the in-launch exchange."""
     _fields_ = [("slot", C.c_void_p * 8), ("wgflags", C.c_void_p * 8), ("err", C.c_void_p), ("rank", C.c_int),
@@ -184,6 +192,10 @@ def _declare_kernels(lib):
     lib.dtf_run_schedule.argtypes = [C.POINTER(ScheduleEntry), i32, vp]
     lib.dtf_run_schedule_steps.argtypes = [C.POINTER(C.POINTER(ScheduleEntry)), C.POINTER(i32), i32, i32, i32, vp]
     lib.dtf_run_schedule_steps.restype = i32
+    lib.dtf_softmax_xent.argtypes = [C.POINTER(XentArgs), vp]
+    lib.dtf_softmax_xent.restype = i32
+    lib.dtf_softmax_xent_blocks.argtypes = [i32]
+    lib.dtf_softmax_xent_blocks.restype = i32
     lib.dtf_gather_cast_transpose.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     for name in ("dtf_small_gemm", "dtf_wgrad_grouped", "dtf_head", "dtf_step_tail", "dtf_sgd_apply", "dtf_adam_apply",
                  "dtf_truncated_normal", "dtf_accumulate", "dtf_kernels_abi_version", "dtf_gemm_tiled",

@@ -106,3 +106,29 @@ def truncated_normal(shape, stddev, generator=None, device="cpu"):
         flat[todo[ok]] = cand[ok]
         todo = todo[~ok]
     return out * stddev
+
+
+def softmax_xent(logits, labels, loss_mode=LOSS_STANDARD, grad_scale=None):
+    """Loss rows, gradient wrt the logits and hit count of softmax cross-entropy over ``[B, C]`` logits; ``labels`` are
+    one-hot / soft rows ``[B, C]`` or class indices ``[B]``.  Same two loss modes as :func:`head`."""
+    b, c = logits.shape
+    z = logits.float()
+    if labels.dim() == 1:
+        lab = torch.zeros_like(z)
+        ok = (labels >= 0) & (labels < c)
+        lab[ok, labels[ok].long()] = 1.0
+        am_l = labels.long()
+    else:
+        lab = labels.float()
+        am_l = lab.argmax(1)
+    scale = (1.0 / b) if grad_scale is None else grad_scale
+    y = torch.softmax(z, 1)
+    if loss_mode == LOSS_REFERENCE:
+        logp = torch.log_softmax(y, 1)
+        p = torch.softmax(y, 1)
+        dy = (p - lab) * scale
+        dz = (dy - (dy * y).sum(1, keepdim=True)) * y
+    else:
+        logp = torch.log_softmax(z, 1)
+        dz = (y - lab) * scale
+    return {"loss_rows": -(lab * logp).sum(1), "dlogits": dz, "correct": int((z.argmax(1) == am_l).sum().item())}
