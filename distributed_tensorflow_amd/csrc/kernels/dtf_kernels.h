@@ -109,6 +109,7 @@ struct DtfXentArgs {
   int ld_logits, ld_labels, ld_dlogits, ld_dlogits_bf;
   int loss_mode;              // 0: reference (softmax applied twice), 1: standard cross-entropy on the logits
   float grad_scale;           // usually 1 / B (mean loss)
+  const int* label_rows;      // optional [B]: batch row i takes row label_rows[i] of the label arrays
 };
 DTF_EXPORT int dtf_softmax_xent(const DtfXentArgs* a, hipStream_t s);
 DTF_EXPORT int dtf_softmax_xent_blocks(int B);
@@ -245,7 +246,7 @@ struct DtfGemmArgs {
 // in the reference runtime).  One call enqueues every entry in order on `s`; stops at the first error
 // and returns  (entry index << 8) | error code.
 enum { DTF_OP_SMALL_GEMM = 1, DTF_OP_HEAD = 2, DTF_OP_WGRAD = 3, DTF_OP_TAIL = 4, DTF_OP_GEMM_TILED = 5, DTF_OP_UPDATE = 6,
-       DTF_OP_MLP2_FWD = 7, DTF_OP_MLP2_BWD = 8, DTF_OP_P2P_UPDATE = 9, DTF_OP_ASYNC_PUSH_PULL = 10, DTF_OP_P2P_SYNC_GENERAL = 11 };
+       DTF_OP_MLP2_FWD = 7, DTF_OP_MLP2_BWD = 8, DTF_OP_P2P_UPDATE = 9, DTF_OP_ASYNC_PUSH_PULL = 10, DTF_OP_P2P_SYNC_GENERAL = 11, DTF_OP_SOFTMAX_XENT = 12 };
 
 // Gradient aggregation + optimizer + parameter redistribution of one synchronous step.
 enum { DTF_UPDATE_LOCAL = 0, DTF_UPDATE_ALLREDUCE = 1, DTF_UPDATE_SHARDED = 2 };

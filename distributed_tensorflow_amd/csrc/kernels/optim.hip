@@ -248,6 +248,7 @@ DTF_EXPORT int dtf_run_schedule(const DtfScheduleEntry* entries, int n, hipStrea
       case DTF_OP_P2P_UPDATE: rc = dtf_p2p_update(static_cast<const DtfP2PUpdateArgs*>(entries[i].args), s); break;
       case DTF_OP_ASYNC_PUSH_PULL: rc = dtf_async_push_pull(static_cast<const DtfAsyncPushPullArgs*>(entries[i].args), s); break;
       case DTF_OP_P2P_SYNC_GENERAL: rc = dtf_p2p_sync_general(static_cast<const DtfP2PGeneralArgs*>(entries[i].args), s); break;
+      case DTF_OP_SOFTMAX_XENT: rc = dtf_softmax_xent(static_cast<const DtfXentArgs*>(entries[i].args), s); break;
       default: rc = DTF_ERR_ARG;
     }
     if (rc != DTF_OK) return (i << 8) | rc;

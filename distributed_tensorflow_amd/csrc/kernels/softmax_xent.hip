@@ -42,8 +42,9 @@ __device__ __forceinline__ int wave_min(int v) {
   return v;
 }
 
-__device__ __forceinline__ float lab_at(const DtfXentArgs& a, int row, int c, long long cls) {
-  return a.labels_f ? a.labels_f[(size_t)row * a.ld_labels + c] : (c == cls ? 1.f : 0.f);
+// `lrow`: row of the label arrays that belongs to batch row `row` (an index gather when label_rows is given)
+__device__ __forceinline__ float lab_at(const DtfXentArgs& a, int lrow, int c, long long cls) {
+  return a.labels_f ? a.labels_f[(size_t)lrow * a.ld_labels + c] : (c == cls ? 1.f : 0.f);
 }
 
 // NE: classes per lane held in registers (C <= 64 * NE); 0 = stream the row from memory in every pass.
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void softmax_xent_kernel(DtfXen
   int hit = 0;
   if (row_ok) {
     const float* z = a.logits + (size_t)row * a.ld_logits;
-    const long long cls = a.labels_i ? a.labels_i[row] : -1;
+    const int lrow = a.label_rows ? a.label_rows[row] : row;
+    const long long cls = a.labels_i ? a.labels_i[lrow] : -1;
     float zr[kRegElems];
     // ---- pass 1: row maximum and its first position ----
     float zmax = NEG_INF;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void softmax_xent_kernel(DtfXen
         if (c < C) {
           s1 += __expf(zr[j] - zmax);
           if (zr[j] == zmax) am_z = min(am_z, c);
-          if (a.labels_f) labmax = fmaxf(labmax, a.labels_f[(size_t)row * a.ld_labels + c]);
+          if (a.labels_f) labmax = fmaxf(labmax, a.labels_f[(size_t)lrow * a.ld_labels + c]);
         }
       }
     } else {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void softmax_xent_kernel(DtfXen
         const float v = z[c];
         s1 += __expf(v - zmax);
         if (v == zmax) am_z = min(am_z, c);
-        if (a.labels_f) labmax = fmaxf(labmax, a.labels_f[(size_t)row * a.ld_labels + c]);
+        if (a.labels_f) labmax = fmaxf(labmax, a.labels_f[(size_t)lrow * a.ld_labels + c]);
       }
     }
     s1 = wave_sum(s1);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void softmax_xent_kernel(DtfXen
       labmax = wave_max(labmax);
       int cand = 0x7fffffff;
       for (int c = lane; c < C; c += 64)
-        if (a.labels_f[(size_t)row * a.ld_labels + c] == labmax) { cand = c; break; }
+        if (a.labels_f[(size_t)lrow * a.ld_labels + c] == labmax) { cand = c; break; }
       am_l = wave_min(cand);
     } else {
       am_l = (int)cls;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void softmax_xent_kernel(DtfXen
       // ---- standard cross-entropy on the logits ----
       float l = 0.f;
       auto body = [&](int c, float v) {
-        const float lab = lab_at(a, row, c, cls);
+        const float lab = lab_at(a, lrow, c, cls);
         l -= lab * ((v - zmax) - log_s1);
         const float g = (__expf(v - zmax) * inv1 - lab) * a.grad_scale;
         if (dz) dz[c] = g;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void softmax_xent_kernel(DtfXen
       float l = 0.f, dot = 0.f;
       auto first = [&](int c, float v) {
         const float y = __expf(v - zmax) * inv1;
-        const float lab = lab_at(a, row, c, cls);
+        const float lab = lab_at(a, lrow, c, cls);
         l -= lab * ((y - ymax) - log_s2);
         dot += (__expf(y - ymax) * inv2 - lab) * a.grad_scale * y;
       };
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void softmax_xent_kernel(DtfXen
       if (dz || dzb) {
         auto second = [&](int c, float v) {
           const float y = __expf(v - zmax) * inv1;
-          const float dy = (__expf(y - ymax) * inv2 - lab_at(a, row, c, cls)) * a.grad_scale;
+          const float dy = (__expf(y - ymax) * inv2 - lab_at(a, lrow, c, cls)) * a.grad_scale;
           const float g = (dy - dot) * y;
           if (dz) dz[c] = g;
           if (dzb) dzb[c] = __float2bfloat16(g);

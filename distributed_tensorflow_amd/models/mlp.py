@@ -71,7 +71,10 @@ class MLPProgram:
         self.names = hidden_names(len(self.hidden))
         self.hact = [torch.zeros((max(self.R, 128), h), dtype=f32, device=dev) for h in self.hidden]
         self.dz = [torch.zeros((batch, h), dtype=f32, device=dev) for h in self.hidden]
-        self.dz2 = torch.zeros((batch, 16), dtype=f32, device=dev)
+        self.dz2 = torch.zeros((batch, 16 if classes <= 16 else classes), dtype=f32, device=dev)
+        # more than 16 classes: the last layer runs as GEMM + general softmax cross-entropy kernel + masked GEMM
+        # (ops.head dispatches), enqueued op by op instead of through the prebuilt native schedule
+        self.wide_head = classes > 16
         self.nblk = (self.R + 15) // 16
         self.loss_part = torch.zeros(self.nblk, dtype=f32, device=dev)
         self.correct_part = torch.zeros(self.nblk, dtype=i32, device=dev)
@@ -141,9 +144,10 @@ class MLPProgram:
 
     def _build_args(self, q: int):
         st = self.state
-        head = ops.build_head_args(self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B,
-                                   self.loss_mode, rows=self.ridx[q], dz2=self.dz2, dz1=self.dz[-1],
-                                   loss_part=self.loss_part, correct_part=self.correct_part, post_part=self.post_part)
+        head = None if self.wide_head else ops.build_head_args(
+            self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B, self.loss_mode,
+            rows=self.ridx[q], dz2=self.dz2, dz1=self.dz[-1], loss_part=self.loss_part, correct_part=self.correct_part,
+            post_part=self.post_part)
         items = self._wgrad_items(q)
         wgrad = ops.build_wgrad_args(items, lr=st.lr if self.fused else None, tail=self._tail(q))
         out = {"head": head, "wgrad": wgrad, "items": items}
@@ -281,7 +285,7 @@ class MLPProgram:
         """Enqueue one full training step on the current stream (no host synchronisation)."""
         q = self.steps_enqueued % self.P
         st, rows = self.state, self.ridx[q]
-        if self.is_cuda:
+        if self.is_cuda and not self.wide_head:
             self._compute_schedule(q).run()
         else:
             x = self.data.images
@@ -295,8 +299,11 @@ class MLPProgram:
             for l in range(len(self.names) - 1, 0, -1):
                 ops.linear_bwd_data(self.dz[l], st.var(f"{self.names[l]}_w"), act=self.hact[l - 1], out=self.dz[l - 1],
                                     m=self.B)
-            ops.wgrad_grouped(self._wgrad_items(q), lr=st.lr if self.fused else None)
-            self._tail_cpu(q, init_only=False)
+            if self.is_cuda:
+                ops.wgrad_grouped(self._args[q]["items"], args=self._args[q]["wgrad"])      # with the step tail
+            else:
+                ops.wgrad_grouped(self._wgrad_items(q), lr=st.lr if self.fused else None)
+                self._tail_cpu(q, init_only=False)
         if self.after_compute is not None:
             self.after_compute()
         self.steps_enqueued += 1

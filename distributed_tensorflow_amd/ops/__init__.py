@@ -267,11 +267,46 @@ def head(hact, w2, b2, labels, m_total, m_train, loss_mode=LOSS_REFERENCE, rows=
                 t.zero_()
                 t[0] = v
         return r
+    if args is None and w2.shape[1] > 16:
+        return _head_wide(hact, w2, b2, labels, m_total, m_train, loss_mode, rows, dz2, dz1, probs, loss_part,
+                          correct_part, post_part, dz1_bf, dz1_bf_t)
     if args is None:
         args = build_head_args(hact, w2, b2, labels, m_total, m_train, loss_mode, rows, dz2, dz1, probs, loss_part,
                                correct_part, post_part, dz1_bf, dz1_bf_t)
     _lib.check(_lib.kernels().dtf_head(C.byref(args), _lib.stream_handle()), "head")
     return args
+
+
+def _head_wide(hact, w2, b2, labels, m_total, m_train, loss_mode, rows, dz2, dz1, probs, loss_part, correct_part, post_part,
+               dz1_bf, dz1_bf_t):
+    """The last layer with more than 16 classes (beyond the one-workgroup head kernel): logits by the small GEMM,
+    loss / gradient / hit counts by the general softmax cross-entropy kernel (training rows with gradient, the
+    accuracy-only rows without), dz1 by the masked backward GEMM.  Same outputs as the head kernel; the partial
+    arrays receive their sums in entry 0."""
+    if probs is not None or dz1_bf is not None or dz1_bf_t is not None:
+        raise ValueError("head: probabilities / bf16 gradients are only produced for at most 16 classes")
+    c = w2.shape[1]
+    z = linear_fwd(hact, w2, b2, relu=False, m=m_total)
+    for t in (loss_part, correct_part, post_part):
+        if t is not None:
+            t.zero_()
+    if m_train > 0:
+        if dz2 is not None and (dz2.shape[0] < m_train or dz2.shape[1] < c):
+            raise ValueError("head: dz2 must be [>=m_train, >=C]")
+        g = dz2[:m_train, :c] if dz2 is not None else None
+        r = softmax_xent(z[:m_train], labels if rows is not None else labels[:m_train], loss_mode,
+                         grad_scale=1.0 / m_train, want_grad=g is not None, dlogits=g, label_rows=rows)
+        if loss_part is not None:
+            loss_part[0:1].copy_(r.loss_sum.reshape(1))
+        if correct_part is not None:
+            correct_part[0:1].copy_(r.correct.reshape(1))
+        if dz1 is not None:
+            linear_bwd_data(g, w2, act=hact, out=dz1, m=m_train)
+    if m_total > m_train and post_part is not None:
+        r = softmax_xent(z[m_train:m_total], labels if rows is not None else labels[m_train:m_total], loss_mode,
+                         want_grad=False, label_rows=None if rows is None else rows[m_train:m_total])
+        post_part[0:1].copy_(r.correct.reshape(1))
+    return None
 
 
 class XentResult:
@@ -292,7 +327,7 @@ class XentResult:
 
 
 def softmax_xent(logits, labels, loss_mode=LOSS_STANDARD, grad_scale=None, want_grad=True, dlogits=None, dlogits_bf=None,
-                 loss_rows=None, loss_part=None, correct_part=None) -> XentResult:
+                 loss_rows=None, loss_part=None, correct_part=None, label_rows=None, _build_only=False) -> XentResult:
     """Fused softmax cross-entropy for ANY class count (K3-K5 of the reference graph beyond the 16-class head
     kernel; ``csrc/kernels/softmax_xent.hip``): loss, gradient wrt the logits (scaled by ``grad_scale``, default
     ``1/B``) and the argmax hit count in one pass.  ``labels``: float ``[B, C]`` (one-hot / soft) or int64 ``[B]``
@@ -301,14 +336,19 @@ def softmax_xent(logits, labels, loss_mode=LOSS_STANDARD, grad_scale=None, want_
     if logits.dim() != 2 or logits.dtype != torch.float32:
         raise ValueError("softmax_xent: logits must be float32 [B, C]")
     b, c = logits.shape
+    if label_rows is not None and (label_rows.dtype != torch.int32 or label_rows.numel() < b):
+        raise ValueError("softmax_xent: label_rows must be int32 [>=B]")
+    nlab = b if label_rows is None else labels.shape[0]
     if labels.dim() == 2:
-        if tuple(labels.shape) != (b, c) or labels.dtype != torch.float32:
+        if tuple(labels.shape) != (nlab, c) or labels.dtype != torch.float32:
             raise ValueError("softmax_xent: label rows must be float32 [B, C]")
-    elif labels.dim() != 1 or labels.numel() != b or labels.dtype != torch.int64:
+    elif labels.dim() != 1 or labels.numel() != nlab or labels.dtype != torch.int64:
         raise ValueError("softmax_xent: class indices must be int64 [B]")
     scale = (1.0 / b) if grad_scale is None else float(grad_scale)
     dev = logits.device
     if not logits.is_cuda:
+        if label_rows is not None:
+            labels = labels.index_select(0, label_rows[:b].long())
         r = reference.softmax_xent(logits, labels, loss_mode, scale)
         lp = torch.zeros(1, dtype=torch.float32) if loss_part is None else loss_part.zero_()
         cp = torch.zeros(1, dtype=torch.int32) if correct_part is None else correct_part.zero_()
@@ -337,7 +377,7 @@ def softmax_xent(logits, labels, loss_mode=LOSS_STANDARD, grad_scale=None, want_
             raise ValueError(f"softmax_xent: {name} must be {dt} [>=B, C], row-major")
     if logits.stride(1) != 1 or (labels.dim() == 2 and labels.stride(1) != 1):
         raise ValueError("softmax_xent: operands must be row-major")
-    _same_device(logits, labels, dlogits, dlogits_bf, loss_rows, loss_part, correct_part)
+    _same_device(logits, labels, dlogits, dlogits_bf, loss_rows, loss_part, correct_part, label_rows)
     args = _lib.XentArgs(logits=logits.data_ptr(), labels_f=labels.data_ptr() if labels.dim() == 2 else None,
                          labels_i=labels.data_ptr() if labels.dim() == 1 else None, dlogits=_lib.ptr(dlogits),
                          dlogits_bf=_lib.ptr(dlogits_bf), loss_rows=_lib.ptr(loss_rows), loss_part=loss_part.data_ptr(),
@@ -345,7 +385,9 @@ def softmax_xent(logits, labels, loss_mode=LOSS_STANDARD, grad_scale=None, want_
                          ld_labels=labels.stride(0) if labels.dim() == 2 else 0,
                          ld_dlogits=0 if dlogits is None else dlogits.stride(0),
                          ld_dlogits_bf=0 if dlogits_bf is None else dlogits_bf.stride(0), loss_mode=int(loss_mode),
-                         grad_scale=scale)
+                         grad_scale=scale, label_rows=_lib.ptr(label_rows))
+    if _build_only:
+        return XentResult(loss_part[:nblk], correct_part[:nblk], loss_rows, dlogits, dlogits_bf, args)
     _lib.check(lib.dtf_softmax_xent(C.byref(args), _lib.stream_handle()), "softmax_xent")
     return XentResult(loss_part[:nblk], correct_part[:nblk], loss_rows, dlogits, dlogits_bf, args)
 

@@ -94,7 +94,7 @@ class XentArgs(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("labels_f", C.c_void_p), ("labels_i", C.c_void_p), ("dlogits", C.c_void_p),
                 ("dlogits_bf", C.c_void_p), ("loss_rows", C.c_void_p), ("loss_part", C.c_void_p), ("correct_part", C.c_void_p),
                 ("B", C.c_int), ("C", C.c_int), ("ld_logits", C.c_int), ("ld_labels", C.c_int), ("ld_dlogits", C.c_int),
-                ("ld_dlogits_bf", C.c_int), ("loss_mode", C.c_int), ("grad_scale", C.c_float)]
+                ("ld_dlogits_bf", C.c_int), ("loss_mode", C.c_int), ("grad_scale", C.c_float), ("label_rows", C.c_void_p)]
 
 
 class Mlp2Peer(C.Structure):
@@ -128,6 +128,7 @@ class Mlp2Args(C.Structure):
 
 
 OP_SMALL_GEMM, OP_HEAD, OP_WGRAD, OP_TAIL, OP_GEMM_TILED, OP_UPDATE, OP_MLP2_FWD, OP_MLP2_BWD = 1, 2, 3, 4, 5, 6, 7, 8
+OP_SOFTMAX_XENT = 12
 
 
 class ScheduleEntry(C.Structure):

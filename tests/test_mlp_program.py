@@ -298,3 +298,49 @@ def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch, fused, one_rank_r
     for a, b in zip(prog_p.read_log(0, 30), prog_f.read_log(0, 30)):
         assert abs(a.loss - b.loss) < 1e-5 and a.global_step == b.global_step
     torch.testing.assert_close(st_p.params, st_f.params, rtol=1e-5, atol=1e-6)
+
+
+def _make_classes(device, classes, hidden=(48,), batch=40, post=True, use_graphs=None):
+    """A program over synthetic data with `classes` label columns (beyond the 16 of the one-workgroup head kernel)."""
+    import numpy as np
+    from distributed_tensorflow_amd.data.mnist import DataSet
+    from distributed_tensorflow_amd.parallel.sharded_state import ShardedState, mlp_variables
+    rng = np.random.RandomState(3)
+    n = 400
+    images = rng.rand(n, 784).astype(np.float32)
+    lab = rng.randint(0, classes, n)
+    labels = np.zeros((n, classes), np.float32)
+    labels[np.arange(n), lab] = 1.0
+    split = DataSet(images, labels, seed=1)
+    st = ShardedState(mlp_variables(784, list(hidden), classes), device, lr=0.2)
+    st.initialize(seed=4)
+    prog = MLPProgram(st, DeviceDataset(split, device, shuffle_seed=2), batch, list(hidden), classes=classes,
+                      loss_mode=ops.LOSS_STANDARD, post_update_accuracy=post, fused_update=True, use_graphs=use_graphs)
+    return st, prog
+
+
+def test_cpu_program_with_40_classes_trains():
+    st, prog = _make_classes("cpu", 40)
+    prog.run(12)
+    recs = prog.read_log(0, 12)
+    assert abs(recs[0].loss - np.log(40)) < 0.5 and recs[-1].loss < recs[0].loss
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("classes,graphs", [(17, False), (40, True), (1000, True)])
+def test_gpu_program_with_more_than_16_classes_matches_cpu(classes, graphs):
+    """The last layer beyond 16 classes: small GEMM + general softmax cross-entropy kernel + masked GEMM, also
+    captured in step graphs; same trajectory as the CPU statements."""
+    steps = 9
+    st_c, prog_c = _make_classes("cpu", classes)
+    st_g, prog_g = _make_classes("cuda", classes, use_graphs=graphs)
+    st_g.load_values({n: st_c.var(n) for n in st_c.names()})
+    prog_c.run(steps)
+    prog_g.run(steps, graph_steps=4)
+    for a, b in zip(prog_c.read_log(0, steps), prog_g.read_log(0, steps)):
+        assert abs(a.loss - b.loss) < 2e-4 and a.global_step == b.global_step
+        assert abs(a.train_correct - b.train_correct) <= 1
+        if a.post_correct is not None:
+            assert abs(a.post_correct - b.post_correct) <= 1
+    for n in st_c.names():
+        torch.testing.assert_close(st_g.var(n).cpu(), st_c.var(n), rtol=2e-3, atol=2e-5)
