@@ -45,6 +45,22 @@ class StepRecord:
         return c / float(self.batch)
 
 
+class _no_gc:
+    """Collect garbage now, then keep the cyclic collector off for the duration of the block (a stream capture)."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 def hidden_names(n_hidden: int) -> List[str]:
     return ["hid" if i == 0 else f"hid{i + 1}" for i in range(n_hidden)]
 
@@ -341,11 +357,16 @@ class MLPProgram:
         g = self._graphs.get(key)
         if g is None:
             saved = self.steps_enqueued
-            # warm the kernels once outside capture is not needed: nothing here allocates or JIT-compiles
+            # warm the kernels once outside capture is not needed: nothing here allocates or JIT-compiles.
+            # The cyclic garbage collector must not run inside the capture: if it finds an older program there, that
+            # program's hipGraphs are destroyed while this stream is capturing, which HIP refuses (an abort from the
+            # destructor) or, worse, lets through with a damaged capture (observed: a replayed graph whose first steps
+            # computed on stale buffers).  Collect first, then keep the collector off until the capture has ended.
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                for _ in range(n):
-                    self.enqueue_step()
+            with _no_gc():
+                with torch.cuda.graph(g):
+                    for _ in range(n):
+                        self.enqueue_step()
             self.steps_enqueued = saved   # capture enqueues nothing
             self._graphs[key] = g
         return g

@@ -234,8 +234,10 @@ class TorchModuleProgram:
             torch.cuda.current_stream(self.device).wait_stream(stream)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                self._step_body(self._gx, self._gy)
+            from .mlp import _no_gc
+            with _no_gc():                                    # no destructor of an older graph inside the capture
+                with torch.cuda.graph(graph, stream=stream):
+                    self._step_body(self._gx, self._gy)
             self._graph = graph
         except Exception as e:                                # noqa: BLE001 - any capture problem means: stay eager
             warnings.warn(f"step capture failed ({type(e).__name__}: {e}); running the module eagerly")
