@@ -82,7 +82,7 @@ class Server:
         from ..parallel import host_ps
         if self.role.is_ps:
             host, port = parse_host_port(self.address)
-            self.ps_service = host_ps.ParameterService(port, self.role.num_workers)
+            self.ps_service = host_ps.ParameterService(port, self.role.num_workers, host)
             self.ps_service.start()
 
     # ------------------------------------------------------------------ ps role

@@ -61,6 +61,12 @@ enum Op : uint32_t {
   OP_WORKER_DONE = 17,  //                                           -> value = workers finished so far
 };
 
+// limits on what a request may ask for (the service trusts no size that arrives over the wire)
+constexpr uint64_t kMaxNameBytes = 4096;
+constexpr int64_t kMaxVariableElems = int64_t(1) << 32;      // 16 GiB of fp32 per variable
+constexpr size_t kMaxVariables = 1 << 16;
+constexpr uint32_t kMaxTokensPerCall = 1 << 16;
+
 #pragma pack(push, 1)
 struct ReqHeader {
   uint32_t magic, op, var, aux;
@@ -148,19 +154,28 @@ void serve_connection(Server* s, int fd) {
   for (;;) {
     ReqHeader h;
     if (!read_full(fd, &h, sizeof(h)) || h.magic != kMagic) break;
-    if (h.nbytes > (uint64_t(1) << 34)) break;
-    buf.resize(h.nbytes);
-    if (h.nbytes && !read_full(fd, buf.data(), h.nbytes)) break;
+    // Sizes come from the wire: nothing is allocated or read before they have been checked against what the
+    // operation can legitimately carry (a variable's bytes, a name), and a request that fails the check ends
+    // the connection - the stream cannot be resynchronised behind a payload that is not going to be read.
     Variable* v = nullptr;
     const bool needs_var = h.op == OP_INIT || h.op == OP_PULL || h.op == OP_PUSH_ASYNC || h.op == OP_ACC_APPLY ||
                            h.op == OP_TAKE_APPLY || h.op == OP_ACC_SET_STEP;
     if (needs_var) {
       std::lock_guard<std::mutex> lk(s->mu);
-      if (h.var >= s->vars.size()) {
-        respond(fd, 2, 0, 0, nullptr, 0);
-        continue;
-      }
-      v = s->vars[h.var].get();
+      if (h.var < s->vars.size()) v = s->vars[h.var].get();
+    }
+    uint64_t max_payload = 0;
+    if (h.op == OP_REGISTER) max_payload = kMaxNameBytes;
+    else if (v && (h.op == OP_INIT || h.op == OP_PUSH_ASYNC || h.op == OP_ACC_APPLY)) max_payload = v->value.size() * sizeof(float);
+    if (h.nbytes > max_payload) {
+      respond(fd, 3, 0, 0, nullptr, 0);
+      break;
+    }
+    buf.resize(h.nbytes);
+    if (h.nbytes && !read_full(fd, buf.data(), h.nbytes)) break;
+    if (needs_var && !v) {
+      respond(fd, 2, 0, 0, nullptr, 0);
+      continue;
     }
     switch (h.op) {
       case OP_REGISTER: {
@@ -169,11 +184,20 @@ void serve_connection(Server* s, int fd) {
         auto it = s->by_name.find(name);
         uint32_t id;
         if (it == s->by_name.end()) {
+          if (h.value <= 0 || h.value > kMaxVariableElems || name.empty() || s->vars.size() >= kMaxVariables) {
+            respond(fd, 3, 0, 0, nullptr, 0);
+            break;
+          }
           id = uint32_t(s->vars.size());
           std::unique_ptr<Variable> nv(new Variable);
           nv->name = name;
-          nv->value.assign(size_t(h.value), 0.f);
-          nv->acc_sum.assign(size_t(h.value), 0.f);
+          try {
+            nv->value.assign(size_t(h.value), 0.f);
+            nv->acc_sum.assign(size_t(h.value), 0.f);
+          } catch (const std::exception&) {         // out of memory: an error status, not a dead ps
+            respond(fd, 5, 0, 0, nullptr, 0);
+            break;
+          }
           s->vars.push_back(std::move(nv));
           s->by_name[name] = id;
         } else {
@@ -265,6 +289,7 @@ void serve_connection(Server* s, int fd) {
         break;
       }
       case OP_TOKEN_ENQUEUE: {
+        if (h.aux > kMaxTokensPerCall) { respond(fd, 3, 0, 0, nullptr, 0); break; }
         {
           std::lock_guard<std::mutex> lk(s->tok_mu);
           for (uint32_t i = 0; i < h.aux; ++i) s->tokens.push_back(h.value);
@@ -316,6 +341,16 @@ void serve_connection(Server* s, int fd) {
       default: respond(fd, 1, 0, 0, nullptr, 0); break;
     }
   }
+  {
+    // forget the descriptor before closing it: stop() must never shut down a number the process has reused since
+    std::lock_guard<std::mutex> lk(s->mu);
+    for (size_t i = 0; i < s->conn_fds.size(); ++i)
+      if (s->conn_fds[i] == fd) {
+        s->conn_fds[i] = s->conn_fds.back();
+        s->conn_fds.pop_back();
+        break;
+      }
+  }
   ::close(fd);
 }
 
@@ -342,7 +377,8 @@ struct Client {
 
 }  // namespace
 
-DTF_RT_EXPORT void* dtf_ps_server_start(int port, int* actual_port) {
+// `bind_host`: dotted IPv4 address to listen on (the task's own entry of --ps_hosts); null or empty = every interface.
+DTF_RT_EXPORT void* dtf_ps_server_start_on(const char* bind_host, int port, int* actual_port) {
   std::unique_ptr<Server> s(new Server);
   s->listen_fd = ::socket(AF_INET, SOCK_STREAM, 0);
   if (s->listen_fd < 0) return nullptr;
@@ -351,6 +387,10 @@ DTF_RT_EXPORT void* dtf_ps_server_start(int port, int* actual_port) {
   sockaddr_in addr{};
   addr.sin_family = AF_INET;
   addr.sin_addr.s_addr = htonl(INADDR_ANY);
+  if (bind_host && *bind_host && inet_pton(AF_INET, bind_host, &addr.sin_addr) != 1) {
+    ::close(s->listen_fd);
+    return nullptr;
+  }
   addr.sin_port = htons(uint16_t(port));
   if (::bind(s->listen_fd, reinterpret_cast<sockaddr*>(&addr), sizeof(addr)) < 0 || ::listen(s->listen_fd, 128) < 0) {
     ::close(s->listen_fd);
@@ -363,6 +403,8 @@ DTF_RT_EXPORT void* dtf_ps_server_start(int port, int* actual_port) {
   s->accept_thread = std::thread(accept_loop, s.get());
   return s.release();
 }
+
+DTF_RT_EXPORT void* dtf_ps_server_start(int port, int* actual_port) { return dtf_ps_server_start_on(nullptr, port, actual_port); }
 
 // Blocks until a client sends SHUTDOWN (the counterpart of server.join(), which the reference never leaves).
 // Returns 1 when shut down, 0 on timeout (timeout_s < 0 waits forever).

@@ -33,7 +33,10 @@ class _Flag:
             return text
         if self.kind == "integer":
             try:
-                return int(text, 0)
+                # decimal unless the value carries a 0x / 0o / 0b prefix: "--task_index=01" is 1, as absl reads it
+                t = text.strip()
+                body = t.lstrip("+-").lower()
+                return int(t, 0) if body[:2] in ("0x", "0o", "0b") else int(t, 10)
             except ValueError:
                 raise FlagError(f"flag --{self.name}={text!r}: invalid integer")
         if self.kind == "float":
@@ -198,7 +201,7 @@ def define_framework_flags(fv: FlagValues = FLAGS) -> None:
                   "allow_soft_placement), 'gpu' or 'cpu'", fv)
     DEFINE_string('ps_backend', 'auto', "Where parameter-server state lives: 'hbm' (sharded across the worker GPUs, "
                   "collectives over xGMI), 'host' (ps processes run the native TCP parameter service, the reference's "
-                  "topology) or 'auto' (hbm when every worker is local to this node and no ps process is needed)", fv)
+                  "topology) or 'auto' (hbm when every entry of --worker_hosts names this machine, else host)", fv)
     DEFINE_string('model', 'mlp', "Model: 'mlp' (the reference 784-H-10 network), 'wide_mlp' or 'resnet50'", fv)
     DEFINE_string('optimizer', 'sgd', "Optimizer: 'sgd' (reference) or 'adam'", fv)
     DEFINE_string('loss', 'reference', "'reference' reproduces the script's softmax-applied-twice loss; 'standard' is "

@@ -51,6 +51,8 @@ def _rt():
     if not _declared:
         lib.dtf_ps_server_start.restype = C.c_void_p
         lib.dtf_ps_server_start.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        lib.dtf_ps_server_start_on.restype = C.c_void_p
+        lib.dtf_ps_server_start_on.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
         lib.dtf_ps_server_wait.restype = C.c_int
         lib.dtf_ps_server_wait.argtypes = [C.c_void_p, C.c_double]
         lib.dtf_ps_server_stop.restype = None
@@ -70,15 +72,19 @@ def _rt():
 class ParameterService:
     """One ps task: owns its variables, accumulators, the token queue and global_step."""
 
-    def __init__(self, port: int, num_workers: int = 0):
+    def __init__(self, port: int, num_workers: int = 0, host: str = ""):
+        """``host``: the address of this task in ``--ps_hosts``; the service listens there only (a dotted IPv4 address;
+        anything else, e.g. a host name or an empty string, listens on every interface)."""
         self.port, self.num_workers = port, num_workers
+        import re
+        self.host = host if re.fullmatch(r"\d+\.\d+\.\d+\.\d+", host or "") else ""
         self._h = None
 
     def start(self) -> int:
         actual = C.c_int(0)
-        self._h = _rt().dtf_ps_server_start(self.port, C.byref(actual))
+        self._h = _rt().dtf_ps_server_start_on(self.host.encode() or None, self.port, C.byref(actual))
         if not self._h:
-            raise OSError(f"parameter service could not listen on port {self.port}")
+            raise OSError(f"parameter service could not listen on {self.host or '*'}:{self.port}")
         self.port = actual.value
         return self.port
 
@@ -312,9 +318,15 @@ def run_role(role: Role, device, datasets, FLAGS) -> int:
     from ..models.mlp import MLPProgram, build_mlp_state
     from ..supervisor.supervisor import Supervisor
 
+    # what this backend trains is the reference configuration: say so instead of silently ignoring a flag
+    unsupported = [f"--{n}={getattr(FLAGS, n)}" for n, dflt in (("optimizer", "sgd"), ("model", "mlp"), ("dtype", "fp32"))
+                   if getattr(FLAGS, n) != dflt]
+    if unsupported:
+        raise ValueError("--ps_backend=host trains the reference MLP with SGD in fp32; not supported there: "
+                         + " ".join(unsupported))
     if role.is_ps:
-        _, port = parse_host_port(role.address)
-        svc = ParameterService(port, role.num_workers)
+        host, port = parse_host_port(role.address)
+        svc = ParameterService(port, role.num_workers, host)
         svc.start()
         svc.wait()                                             # server.join()
         time.sleep(0.2)                                        # let the last responses drain
@@ -326,8 +338,10 @@ def run_role(role: Role, device, datasets, FLAGS) -> int:
     is_chief = role.is_chief
     hidden = [FLAGS.hidden_units] * max(1, FLAGS.hidden_layers)
     state = build_mlp_state(train.IMAGE_PIXELS ** 2, hidden, 10, device, optimizer="sgd", lr=FLAGS.learning_rate)
-    data = DeviceDataset(datasets.train, device, shuffle_seed=FLAGS.seed * 7919 + role.task_index)
+    data = DeviceDataset(datasets.train, device, shuffle_seed=train.shuffle_seed(FLAGS.seed, role.task_index))
     loss_mode = ops.LOSS_REFERENCE if FLAGS.loss == "reference" else ops.LOSS_STANDARD
+    # (the training accuracy of a step is the one of its training pass: the parameters live on the ps, a second
+    # pass would need a second pull; --post_update_accuracy has no effect on this backend)
     prog = MLPProgram(state, data, FLAGS.batch_size, hidden, loss_mode=loss_mode, fused_update=False,
                       post_update_accuracy=False, gs_inc=0)
     engine = HostPSEngine(prog, state, role, sync=FLAGS.sync_replicas, replicas_to_aggregate=FLAGS.replicas_to_aggregate)

@@ -59,6 +59,27 @@ def resolve_device(role: Optional[Role], requested: str) -> torch.device:
     return torch.device("cpu")
 
 
+def shuffle_seed(seed_flag: int, task_index: int) -> int:
+    """Seed of a worker's data shuffle: derived from ``--seed``; with ``--seed=0`` from the clock and the process, like
+    the parameter initialisation (the reference sets no seed anywhere: every run and every worker shuffles differently)."""
+    import os
+    base = seed_flag if seed_flag else ((int(time.time() * 1e6) ^ (os.getpid() << 16)) & 0x3FFFFFFF)
+    return (base * 7919 + task_index) & 0x7FFFFFFF
+
+
+def local_hosts(hosts) -> bool:
+    """True when every ``host:port`` entry names this machine (loopback or one of its own addresses)."""
+    import socket
+    mine = {"localhost", "127.0.0.1", "0.0.0.0", ""}
+    try:
+        name = socket.gethostname()
+        mine.add(name)
+        mine.update(socket.gethostbyname_ex(name)[2])
+    except OSError:
+        pass
+    return all(h.rsplit(":", 1)[0] in mine or h.rsplit(":", 1)[0].startswith("127.") for h in hosts)
+
+
 def _emit(line: str) -> None:
     sys.stdout.write(line + "\n")
 
@@ -190,7 +211,7 @@ def build_worker(role: Optional[Role], device: torch.device, datasets, hidden_un
 
     state = build_mlp_state(IMAGE_PIXELS * IMAGE_PIXELS, hidden, 10, device, world_size=world, rank=rank,
                             optimizer=optimizer, lr=learning_rate)
-    data = DeviceDataset(datasets.train, device, shuffle_seed=(seed * 7919 + rank))
+    data = DeviceDataset(datasets.train, device, shuffle_seed=shuffle_seed(seed, rank))
     loss_mode = ops.LOSS_REFERENCE if loss == "reference" else ops.LOSS_STANDARD
     if sync_replicas or world == 1:
         R = replicas_to_aggregate if (sync_replicas and replicas_to_aggregate is not None) else world
@@ -229,7 +250,12 @@ def main(unused_argv=None) -> int:
     cluster = ClusterSpec({'ps': ps_spec, 'worker': worker_spec})                          # :53
     role = Role(FLAGS.job_name, FLAGS.task_index, cluster)
     device = resolve_device(role, FLAGS.device)
-    ps_backend = FLAGS.ps_backend if FLAGS.ps_backend != "auto" else "hbm"
+    # auto: the parameter-server state lives in the workers' HBM whenever every worker is on this machine (the ps
+    # entries then only name logical shards); workers on other machines need the ps processes of the host backend
+    if FLAGS.ps_backend != "auto":
+        ps_backend = FLAGS.ps_backend
+    else:
+        ps_backend = "hbm" if (FLAGS.single_process or not ps_spec or local_hosts(worker_spec)) else "host"
 
     if ps_backend == "host":
         from .parallel import host_ps

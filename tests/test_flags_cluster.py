@@ -85,3 +85,23 @@ def test_round_robin_variable_placement():
     assert round_robin_placement(names, 1) == {n: 0 for n in names}
     assert round_robin_placement(names, 2) == {"global_step": 0, "hid_w": 1, "hid_b": 0, "sm_w": 1, "sm_b": 0}
     assert round_robin_placement(names, 3)["sm_w"] == 0
+
+
+def test_integers_are_decimal_unless_prefixed():
+    from distributed_tensorflow_amd import flags as F
+    fv = F.FlagValues()
+    F.DEFINE_integer("task_index", None, "", fv)
+    F.DEFINE_integer("mask", 0, "", fv)
+    fv.parse(["--task_index=01", "--mask=0x10"])
+    assert fv.task_index == 1 and fv.mask == 16
+    import pytest
+    with pytest.raises(F.FlagError):
+        fv.parse(["--task_index=1.5"])
+
+
+def test_auto_backend_rule_and_shuffle_seed():
+    from distributed_tensorflow_amd import train
+    assert train.local_hosts(["127.0.0.1:2223", "localhost:2224"])
+    assert not train.local_hosts(["127.0.0.1:2223", "172.16.1.183:2224"])          # a worker elsewhere: ps processes needed
+    assert train.shuffle_seed(7, 0) != train.shuffle_seed(7, 1) and train.shuffle_seed(7, 1) == train.shuffle_seed(7, 1)
+    assert train.shuffle_seed(0, 0) >= 0                                             # from entropy, never the fixed rank

@@ -147,3 +147,36 @@ def test_host_backend_sync_one_ps_two_workers():
     assert s0[-1][2] < s0[0][2] - 0.2
     gs0 = [s[1] for s in s0]
     assert gs0 == sorted(gs0)
+
+
+def test_service_refuses_sizes_it_cannot_trust(service):
+    """Sizes arrive over the wire: a negative or absurd element count, a payload larger than the variable it is
+    for, or a flood of tokens gets an error status (or a closed connection), and the service keeps serving."""
+    _, port = service
+    c = H.PSClient("127.0.0.1", port)
+    for bad in (-1, 0, 1 << 40):
+        with pytest.raises(RuntimeError):
+            c.call(H.OP_REGISTER, value=bad, payload=np.frombuffer(b"w", np.uint8))
+    vid = _reg(c, "v", 8)
+    with pytest.raises(RuntimeError):
+        c.call(H.OP_TOKEN_ENQUEUE, aux=1 << 20, value=1)
+    # a payload that does not fit the variable: refused before it is read, the connection ends
+    with pytest.raises(RuntimeError):
+        c.call(H.OP_INIT, var=vid, payload=np.zeros(1 << 16, np.float32))
+    c.close()
+    d = H.PSClient("127.0.0.1", port)                      # the service is still there
+    assert _reg(d, "v", 8) == vid
+    d.call(H.OP_INIT, var=vid, payload=np.arange(8, dtype=np.float32))
+    out = np.zeros(8, np.float32)
+    d.call(H.OP_PULL, var=vid, out=out)
+    assert np.array_equal(out, np.arange(8, dtype=np.float32))
+    d.close()
+
+
+def test_service_listens_on_its_configured_address_only():
+    svc = H.ParameterService(0, host="127.0.0.1")
+    port = svc.start()
+    c = H.PSClient("127.0.0.1", port)
+    assert c.call(H.OP_GET_STEP)[0] == 1
+    c.close()
+    svc.stop()

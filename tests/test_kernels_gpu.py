@@ -204,9 +204,12 @@ def test_launchers_reject_bad_shapes():
     x, w = torch.zeros(4, 8, device=DEV), torch.zeros(9, 4, device=DEV)
     with pytest.raises(ValueError):
         ops.linear_fwd(x, w)
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):          # label rows narrower than the class count (20 classes: the wide-head path)
         ops.head(torch.zeros(4, 8, device=DEV), torch.zeros(8, 20, device=DEV), torch.zeros(20, device=DEV),
-                 torch.zeros(4, 20, device=DEV), 4, 4)
+                 torch.zeros(4, 19, device=DEV), 4, 4)
+    with pytest.raises(ValueError):          # and in the 16-class head kernel's range
+        ops.head(torch.zeros(4, 8, device=DEV), torch.zeros(8, 10, device=DEV), torch.zeros(10, device=DEV),
+                 torch.zeros(4, 9, device=DEV), 4, 4)
 
 
 @pytest.mark.gpu
