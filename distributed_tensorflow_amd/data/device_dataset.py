@@ -25,6 +25,11 @@ class DeviceDataset:
         # perm[e & 1] holds the row order of epoch e
         self.perm = torch.zeros((2, self.n), dtype=torch.int32, device=self.device) if shuffle else None
         self._resident = [None, None]
+        # permutations travel through page-locked staging buffers owned by this object (one per device buffer): the
+        # source of the upload then stays valid and in place for as long as the copy engine may be reading it
+        self._stage = None
+        if shuffle and self.device.type == "cuda":
+            self._stage = torch.zeros((2, self.n), dtype=torch.int32).pin_memory()
 
     def max_steps_per_launch(self, batch: int) -> int:
         """A launch may touch at most two epochs (one per permutation buffer)."""
@@ -47,5 +52,12 @@ class DeviceDataset:
         for e in range(e_lo, e_hi + 1):
             if self._resident[e & 1] != e:
                 p = torch.from_numpy(epoch_permutation(self.seed, e, self.n))
-                self.perm[e & 1].copy_(p)
+                if self._stage is not None:
+                    # (the launches that may still read the device buffer precede the copy in stream order; the
+                    # staging buffer of this slot was last used two epochs ago and that copy has long completed)
+                    self._stage[e & 1].copy_(p)
+                    self.perm[e & 1].copy_(self._stage[e & 1], non_blocking=True)
+                    torch.cuda.current_stream(self.device).synchronize()
+                else:
+                    self.perm[e & 1].copy_(p)
                 self._resident[e & 1] = e
