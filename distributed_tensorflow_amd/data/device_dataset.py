@@ -17,8 +17,8 @@ from .mnist import DataSet, epoch_permutation
 class DeviceDataset:
     def __init__(self, split: DataSet, device, shuffle_seed: int = 0, shuffle: bool = True):
         self.device = torch.device(device)
-        self.images = torch.from_numpy(split.images).to(self.device)
-        self.labels = torch.from_numpy(split.labels).to(self.device)
+        self.images = self._upload(split.images)
+        self.labels = self._upload(split.labels)
         self.n = split.num_examples
         self.seed = shuffle_seed
         self.shuffle = shuffle
@@ -30,6 +30,19 @@ class DeviceDataset:
         self._stage = None
         if shuffle and self.device.type == "cuda":
             self._stage = torch.zeros((2, self.n), dtype=torch.int32).pin_memory()
+
+    def _upload(self, array) -> torch.Tensor:
+        """Host array -> device tensor through a page-locked copy of our own and an explicit wait, not through the
+        runtime's path for pageable memory: on some machines of the pool a split uploaded that way and read by the very
+        next kernels showed a few stale rows (labels still zero, images of another row), never with this path."""
+        t = torch.from_numpy(array)
+        if self.device.type != "cuda":
+            return t.to(self.device)
+        staged = t.pin_memory()
+        out = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+        out.copy_(staged, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return out
 
     def max_steps_per_launch(self, batch: int) -> int:
         """A launch may touch at most two epochs (one per permutation buffer)."""

@@ -30,7 +30,17 @@ def _entry(rank, world, port, fn, args, q):
 
 
 def run_ranks(fn, world, *args, timeout=100):
-    """Run ``fn(rank, world, port, *args)`` in ``world`` processes; returns results by rank."""
+    """Run ``fn(rank, world, port, *args)`` in ``world`` processes; returns results by rank.  The rendezvous port is
+    picked a moment before the ranks bind it; if somebody else took it in between, one more try on another port."""
+    try:
+        return _run_ranks_once(fn, world, args, timeout)
+    except AssertionError as e:
+        if "EADDRINUSE" not in str(e) and "address already in use" not in str(e):
+            raise
+    return _run_ranks_once(fn, world, args, timeout)
+
+
+def _run_ranks_once(fn, world, args, timeout):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
