@@ -96,7 +96,7 @@ def _select_p2p_transport(engine, prog, args, rank, world, device, graph_steps):
     times = {}
     for mode in ("replicated", "sharded"):
         engine.set_p2p_mode(mode)
-        engine.run(32, graph_steps)                         # captures the graphs, warms the path
+        engine.run(trial, graph_steps)                      # captures the graphs the timed trial replays, warms the path
         times[mode] = _time_segment(engine, device, world, trial, graph_steps)
     best = min(times, key=times.get)                        # the same on every rank: the times are maxima over the ranks
     engine.set_p2p_mode(best)
@@ -148,7 +148,7 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
             and os.environ.get("DTF_P2P_MODE") is None):
         try:
             selection = _select_p2p_transport(engine, prog, args, rank, world, device, graph_steps)
-            extra_steps = 2 * (32 + selection["steps_each"])
+            extra_steps = 4 * selection["steps_each"]
         except RuntimeError as e:                           # a peer wait ran into its limit: raised on every rank
             sys.stderr.write(f"[bench] rank {rank}: transport trial failed ({e})\n")
             failed, selection = 1, None

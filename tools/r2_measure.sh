@@ -24,8 +24,8 @@ DTF_SHARE_GPU=1 DTF_DIST_BACKEND=gloo DTF_P2P_ALLREDUCE=1 run 300 python bench.p
 step "kernel trace of the one-worker step and of the exchange kernels (one rank)"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-run 300 rocprofv3 --kernel-trace --stats -d $R/$out/prof_n1 -- python3 $R/bench.py --gpus 1 --steps 2000 --warmup 200 > $R/$out/prof_n1.json 2>> $R/$out/err.log
-DTF_P2P_ALLREDUCE=1 DTF_P2P_MODE=sharded run 300 rocprofv3 --kernel-trace --stats -d $R/$out/prof_n1_sharded -- python3 $R/bench.py --gpus 1 --steps 2000 --warmup 200 --force_collectives > $R/$out/prof_n1_sharded.json 2>> $R/$out/err.log
+run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_n1 -- python3 $R/bench.py --gpus 1 --steps 2000 --warmup 200 > $R/$out/prof_n1.json 2>> $R/$out/err.log
+DTF_P2P_ALLREDUCE=1 DTF_P2P_MODE=sharded run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof_n1_sharded -- python3 $R/bench.py --gpus 1 --steps 2000 --warmup 200 --force_collectives > $R/$out/prof_n1_sharded.json 2>> $R/$out/err.log
 cd $R
 find $out -name "*kernel_stats.csv" | head
 echo done
