@@ -413,6 +413,29 @@ class MLPProgram:
         finally:
             self.steps_enqueued = saved
 
+    def native_launch_ok(self) -> bool:
+        """Steps of this program can be launched many at a time by the native executor (no Python between them)."""
+        return (self.is_cuda and not self.wide_head and self.after_compute is None and self.phase_period == 1
+                and hasattr(self, "schedule_tail_entries"))
+
+    def run_native(self, n_steps: int) -> None:
+        """``n_steps`` steps enqueued by ONE native call (``dtf_run_schedule_steps``): the device starts a few
+        microseconds after the call, where a graph replay needs 10-16 us to start; the host stays ahead as long as a
+        kernel runs longer than its launch call takes."""
+        if not self._started:
+            self.start()
+        if not self.native_launch_ok():
+            raise RuntimeError("this program's steps need Python between them")
+        self.data.prepare(self.steps_enqueued, n_steps, self.B)
+        saved = self.steps_enqueued
+        scheds = []
+        for q in range(self.P):                       # one schedule per buffer slot, built on first use
+            self.steps_enqueued = q
+            scheds.append(self._compute_schedule(q))
+        self.steps_enqueued = saved
+        ops._lib.run_schedule_steps(scheds, saved % self.P, n_steps)
+        self.steps_enqueued = saved + n_steps
+
     def run(self, n_steps: int, graph_steps: int = 64) -> None:
         """Enqueue ``n_steps`` steps; returns without waiting for the device."""
         if not self._started:

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--lengths", default="5,10,20,40,80,160")
     ap.add_argument("--repeats", type=int, default=15)
     ap.add_argument("--idle_ms", type=float, default=0.0, help="host sleep before each timed run (GPU clocks fall when idle)")
+    ap.add_argument("--launch", default="graph", choices=["graph", "native"],
+                    help="graph: replay prepared hipGraphs; native: one native call launches every kernel of the run")
     a = ap.parse_args()
     from distributed_tensorflow_amd import ops
     from distributed_tensorflow_amd.data import mnist
@@ -42,14 +44,19 @@ def main():
     for n in lengths:
         tot, host = [], []
         for _ in range(a.repeats):
-            prog.prepare_graphs(5, 64)
-            prog.prepare_graphs(n, 64, start_offset=5)
+            if a.launch == "graph":
+                prog.prepare_graphs(5, 64)
+                prog.prepare_graphs(n, 64, start_offset=5)
             eng.run(5, 64)
             torch.cuda.synchronize()
             if a.idle_ms:
                 time.sleep(a.idle_ms * 1e-3)
             t0 = time.perf_counter()
-            eng.run(n, 64)
+            if a.launch == "graph":
+                eng.run(n, 64)
+            else:
+                prog.run_native(n)
+                eng.updates_applied += n
             t1 = time.perf_counter()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
@@ -62,7 +69,8 @@ def main():
     xs, ys = [r["steps"] for r in rows], [r["total_us_median"] for r in rows]
     mx, my = sum(xs) / len(xs), sum(ys) / len(ys)
     slope = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / sum((x - mx) ** 2 for x in xs)
-    print(json.dumps({"rows": rows, "per_step_us": slope, "fixed_us": my - slope * mx, "idle_ms": a.idle_ms}, indent=1))
+    print(json.dumps({"rows": rows, "per_step_us": slope, "fixed_us": my - slope * mx, "idle_ms": a.idle_ms,
+                      "launch": a.launch}, indent=1))
 
 
 if __name__ == "__main__":
