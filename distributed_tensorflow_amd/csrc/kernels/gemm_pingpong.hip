@@ -242,8 +242,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
             *reinterpret_cast<float4*>(&Cf[(size_t)(crow + ha * 64 + R) * p.ldc + ccol + q * 4]) = v;
         }
       } else {
-        // two row groups at a time (6 parameter loads in flight per lane before the first use); the fence keeps
-        // the compiler from hoisting every group's loads to the top, which would not fit the register file
+        // two rows at a time (6 parameter loads in flight per lane before the first use); the fence keeps
+        // the compiler from hoisting every group's loads to the top, which would not fit the register file.
+        // A lane owns the ADJACENT rows 8ib + 2(lane >> 4) + {0, 1}, so that a pair of updated weights of one column
+        // is one 32-bit piece of the transposed copy.
+        unsigned short* const Wt = static_cast<unsigned short*>(p.opt_wt);
 #pragma unroll
         for (int ib = 0; ib < 8; ++ib) {
           __builtin_amdgcn_sched_barrier(0);
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
           bool in[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int R = (ib * 2 + u) * 4 + (lane >> 4), q = lane & 15;
+            const int R = ib * 8 + 2 * (lane >> 4) + u, q = lane & 15;
             gq[u] = *reinterpret_cast<const f32x4*>(&wl[R * 256 + (((q ^ (R >> 2)) & 15) << 4)]);
             in[u] = crow + ha * 64 + R < p.M && ccol + q * 4 < p.N;
             off[u] = in[u] ? (size_t)(crow + ha * 64 + R) * p.ldc + ccol + q * 4 : 0;
@@ -287,6 +290,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
               }
               if (p.opt_w) *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.opt_w) + off[u]) = make_uint2(w01, w23);
             }
+          }
+          if (opt && Wt) {
+            // transposed bf16 image, built in the part of the fp32 image this wave has already consumed (rows
+            // 8ib..8ib+7 = bytes [2048 ib, 2048 ib + 2048) were read above; row group ib of the transposed image is
+            // the 1 KB at 1024 ib): 16-byte chunk (ib, c) = rows 8ib..8ib+7 of column c, at slot
+            // (c & 3)*16 + ((c >> 2) + 2 ib + (c & 1)) % 16, which keeps these stores and the reads below free of
+            // bank conflicts.  LDS operations of one wave complete in order, and the region is private to the wave.
+            const int lr = lane >> 4, q = lane & 15;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int c = 4 * q + e;
+              const unsigned pair = (unsigned)pp_f2bf(pq[0][e]) | ((unsigned)pp_f2bf(pq[1][e]) << 16);
+              *reinterpret_cast<unsigned*>(&wl[ib * 1024 + (((c & 3) << 4) + (((c >> 2) + 2 * ib + (c & 1)) & 15)) * 16 + lr * 4]) = pair;
+            }
+          }
+        }
+        if (opt && Wt) {
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int c = it * 8 + (lane >> 3), rg = lane & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(&wl[rg * 1024 + (((c & 3) << 4) + (((c >> 2) + 2 * rg + (c & 1)) & 15)) * 16]);
+            if (ccol + c < p.N && crow + ha * 64 + rg * 8 < p.M)      // M is a multiple of 8: a chunk is inside or outside
+              *reinterpret_cast<u32x4*>(&Wt[(size_t)(ccol + c) * p.ldwt + crow + ha * 64 + rg * 8]) = v;
           }
         }
       }
@@ -406,7 +432,7 @@ bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a) {
     if (a.epilogue != EPI_WGRAD || (a.opt_m == nullptr) != (a.opt_v == nullptr)) return false;
     if ((reinterpret_cast<uintptr_t>(a.opt_p) & 15) || (a.opt_m && ((reinterpret_cast<uintptr_t>(a.opt_m) | reinterpret_cast<uintptr_t>(a.opt_v)) & 15))) return false;
     if (a.opt_w && (reinterpret_cast<uintptr_t>(a.opt_w) & 7)) return false;
-    if (a.opt_wt) return false;               // the transposed copy is a separate pass over the compute-dtype copy
+    if (a.opt_wt && ((reinterpret_cast<uintptr_t>(a.opt_wt) & 15) || (a.ldwt & 7) || a.ldwt < a.M)) return false;
   }
   return true;
 }

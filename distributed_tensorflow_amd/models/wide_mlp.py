@@ -8,8 +8,9 @@ accumulation and fp32 master weights, or in exact fp32.  Every product is of the
 
 Per step:  gather+cast batch -> L x forward GEMM (+bias, ReLU) -> head (loss, accuracy, dz)
 -> per layer, top down: weight-gradient GEMM (+bias gradient), backward GEMM (ReLU mask) -> small
-kernel for the 10-class layer -> optimizer / collectives.  The compute copies of the weights are
-rebuilt from the fp32 masters at the start of every step.
+kernel for the 10-class layer -> optimizer / collectives.  The compute copies of the weights (W and W^T in the
+compute dtype) are rebuilt from the fp32 masters at the start of a step, except for the layers whose weight-gradient
+epilogue applies the optimizer: that epilogue writes both copies itself.
 
 A layer's gradients are final as soon as its weight-gradient product has been enqueued; ``grad_ready(l)``
 then lets the engine aggregate that layer's bucket on a second stream while the layers below are still
@@ -172,10 +173,9 @@ class WideMLPProgram(MLPProgram):
                 adam = st.optimizer != "sgd"
                 opt = ops.FoldedOptimizer(st.var(wname), st._view(st.m, wname) if adam else None,
                                           st._view(st.v, wname) if adam else None, self.w[l], st.lr, st.beta1, st.beta2,
-                                          st.eps, st.state[2:3], 1)
+                                          st.eps, st.state[2:3], 1, wt=self.w_t[l])
                 ops.gemm_nt(a_t, self.dzc_t[l], st.grad(wname), ops.EPI_WGRAD, bias_out=st.grad(f"{self.names[l]}_b"),
-                            opt=opt)
-                ops.transpose16(self.w[l], self.w_t[l])
+                            opt=opt)            # refreshes W_l and W_l^T (compute dtype) itself
                 continue
             ops.gemm_nt(a_t, self.dzc_t[l], st.grad(wname), ops.EPI_WGRAD,
                         bias_out=st.grad(f"{self.names[l]}_b"))

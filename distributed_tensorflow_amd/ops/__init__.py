@@ -583,11 +583,12 @@ def _dtype_code(t):
 class FoldedOptimizer:
     """What the weight-gradient epilogue needs to apply the optimizer itself (one worker, no aggregation):
     master weights ``p`` (and Adam moments ``m``, ``v``; both None = SGD) shaped like the gradient, the compute-dtype
-    copy ``w`` to refresh, the device step counter (``step_tensor[0] + step_offset`` = number of this update)."""
+    copy ``w`` to refresh (and its transpose ``wt`` [N, >=M], the forward product's operand), the device step counter
+    (``step_tensor[0] + step_offset`` = number of this update)."""
 
     def __init__(self, p, m=None, v=None, w=None, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8, step_tensor=None,
-                 step_offset=0):
-        self.p, self.m, self.v, self.w = p, m, v, w
+                 step_offset=0, wt=None):
+        self.p, self.m, self.v, self.w, self.wt = p, m, v, w, wt
         self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
         self.step_tensor, self.step_offset = step_tensor, step_offset
 
@@ -635,6 +636,8 @@ def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t
                                step_tensor=opt.step_tensor, step_offset=opt.step_offset)
                 if opt.w is not None:
                     opt.w.copy_(opt.p.to(opt.w.dtype))
+                if opt.wt is not None:
+                    opt.wt[:, :M].copy_(opt.p.t().to(opt.wt.dtype))
                 return out
         out[:M].copy_(c.to(out.dtype))
         if out_t is not None:
@@ -682,9 +685,13 @@ def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t
             raise ValueError("gemm_nt: opt.w must be the compute-dtype copy, laid out like the gradient")
         if opt.m is not None and opt.step_tensor is None:
             raise ValueError("gemm_nt: Adam reads its step number from a device counter")
-        _same_device(a, opt.p, opt.m, opt.v, opt.w, opt.step_tensor)
+        if opt.wt is not None and (opt.wt.dtype != a.dtype or opt.wt.shape[0] != N or opt.wt.shape[1] < M
+                                   or opt.wt.stride(1) != 1):
+            raise ValueError("gemm_nt: opt.wt must be the transposed compute-dtype copy [N, >=M]")
+        _same_device(a, opt.p, opt.m, opt.v, opt.w, opt.wt, opt.step_tensor)
         args.opt_p, args.opt_m, args.opt_v = opt.p.data_ptr(), _lib.ptr(opt.m), _lib.ptr(opt.v)
-        args.opt_w, args.opt_wt, args.ldwt = _lib.ptr(opt.w), None, 0
+        args.opt_w, args.opt_wt = _lib.ptr(opt.w), _lib.ptr(opt.wt)
+        args.ldwt = 0 if opt.wt is None else opt.wt.stride(0)
         args.opt_step = None if opt.step_tensor is None else _i32c(opt.step_tensor, "step_tensor").data_ptr()
         args.opt_step_offset = int(opt.step_offset)
         args.opt_lr, args.opt_b1, args.opt_b2, args.opt_eps = float(opt.lr), float(opt.beta1), float(opt.beta2), float(opt.eps)

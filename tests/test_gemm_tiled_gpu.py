@@ -209,10 +209,13 @@ def test_folded_optimizer_epilogue_against_separate_kernels(pingpong_kernel):
         pf, mf, vf = p0.clone(), m0.clone(), v0.clone()
         w = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
         db2, unused = torch.zeros(N, device=DEV), torch.zeros(M, N, device=DEV)
+        wt = torch.zeros(N, M + 8, dtype=torch.bfloat16, device=DEV)       # wider than needed: ldwt != M
         opt = ops.FoldedOptimizer(pf, mf if adam else None, vf if adam else None, w, 1e-3 if adam else 0.05,
-                                  step_tensor=step, step_offset=1)
+                                  step_tensor=step, step_offset=1, wt=wt if adam else None)
         ops.gemm_nt(xt, dyt, unused, ops.EPI_WGRAD, bias_out=db2, opt=opt)
         assert torch.equal(pf, pr) and torch.equal(db2, db) and float(unused.abs().sum()) == 0.0
         assert torch.equal(w, pr.to(torch.bfloat16))
+        if adam:        # the transposed compute copy comes out of the same epilogue; nothing outside [N, M] is written
+            assert torch.equal(wt[:, :M], pr.to(torch.bfloat16).t()) and float(wt[:, M:].abs().sum()) == 0.0
         if adam:
             assert torch.equal(mf, mr) and torch.equal(vf, vr)
