@@ -95,6 +95,41 @@ struct DtfHeadArgs {
   int ld_bf, ld_bf_t;       //     bf16 products, written here instead of by a cast pass over the fp32 dz1 (which may be null)
 };
 
+// Output layer of a wide bf16 network (head_wide.hip): same mathematics as DtfHeadArgs with every row a training row,
+// the last hidden activation given as the bf16 tensors the forward GEMM wrote.
+struct DtfHeadWideArgs {
+  const void* H;            // bf16 [M, ldh] last hidden activation (post-ReLU), row-major; ldh a multiple of 8
+  const void* Ht;           // bf16 [Hd, ldht] the same transposed; ldht a multiple of 4
+  const float* W2;          // [Hd, C]
+  const float* b2;          // [C]
+  const float* labels;      // [rows, C] one-hot / soft labels
+  const int* rows;          // optional gather of label rows
+  float* dz2;               // [M, 16] gradient wrt logits, zero padded to 16 columns
+  void* dz1_bf;             // optional bf16 [M, ld_bf]: gradient wrt the hidden pre-activation (ReLU mask applied) ...
+  void* dz1_bf_t;           // ... and transposed [Hd, ld_bf_t]
+  float* loss_part;         // [ceil(M/16)]
+  int* correct_part;
+  int* post_part;           // optional, zeroed (no accuracy-only rows here)
+  int M, Hd, C;             // M a multiple of 4, Hd a multiple of 8, C <= 16
+  int ldh, ldht, ld_bf, ld_bf_t;
+  int loss_mode;            // 0: reference (softmax applied twice), 1: standard cross-entropy on the logits
+  float inv_b;
+  int pad_;
+};
+DTF_EXPORT int dtf_head_wide(const DtfHeadWideArgs* a, hipStream_t s);
+
+// dW2 = H^T dz2, db2 = colsum(dz2) for that layer, plus the step tail in one extra workgroup.
+struct DtfOutWgradWideArgs {
+  const void* Ht;           // bf16 [Hd, ldht], ldht a multiple of 8
+  const float* dz2;         // [B, 16]
+  float* dW;                // [Hd, C] (ldw)
+  float* db;                // [C]
+  int Hd, C, B;             // B a multiple of 8
+  int ldht, ldw, pad_;
+  DtfTailArgs tail;
+};
+DTF_EXPORT int dtf_out_wgrad_wide(const DtfOutWgradWideArgs* a, hipStream_t s);
+
 // Fused softmax cross-entropy over [B, C] logits for any C (softmax_xent.hip): loss, gradient, accuracy count.
 struct DtfXentArgs {
   const float* logits;        // [B, ld_logits]

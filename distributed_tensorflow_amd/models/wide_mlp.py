@@ -18,6 +18,7 @@ being differentiated (``parallel/bucketed.py``).
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -57,6 +58,11 @@ class WideMLPProgram(MLPProgram):
         self.refresh_compute_copies()
         self.grad_ready = None              # engine hook: called with a bucket index of grad_groups()
         self.folded = [False] * len(hidden)  # layers whose weight-gradient epilogue applies the optimizer itself
+        # bf16 on the GPU: the output layer's kernels read the bf16 activation and its transpose as the last forward
+        # product wrote them (16-wave kernels of csrc/kernels/head_wide.hip); otherwise the fp32 copy and the 4-wave
+        # kernels shared with the reference model.  DTF_WIDE_HEAD=0 selects the latter for comparison.
+        self.bf16_head = (self.is_cuda and T == torch.bfloat16 and self.R == self.B and os.environ.get("DTF_WIDE_HEAD", "1") != "0"
+                          and ops.head_wide_bf16_takes(B, hidden[-1], classes) and self._head_writes_bf16())
         del self.schedule_tail_entries      # this program enqueues op by op; the engine then uses after_compute
         if self.is_cuda:
             self._args = [self._build_args(q) for q in range(self.P)]      # now with the compute-dtype buffers
@@ -78,6 +84,14 @@ class WideMLPProgram(MLPProgram):
 
     def _build_args(self, q: int):
         st = self.state
+        if getattr(self, "bf16_head", False):
+            head = ops.build_head_wide_args(self.h[-1], self.hl_t, st.var("sm_w"), st.var("sm_b"), self.data.labels, self.B,
+                                            self.loss_mode, rows=self.ridx[q], dz2=self.dz2, dz1_bf=self.dzc[-1],
+                                            dz1_bf_t=self.dzc_t[-1], loss_part=self.loss_part,
+                                            correct_part=self.correct_part, post_part=self.post_part)
+            wgrad = ops.build_out_wgrad_wide_args(self.hl_t, self.dz2, st.grad("sm_w"), st.grad("sm_b"), self.B,
+                                                  tail=self._tail(q))
+            return {"head": head, "wgrad": wgrad, "items": None}
         head = ops.build_head_args(self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B,
                                    self.loss_mode, rows=self.ridx[q], dz2=self.dz2, **self._head_dz(),
                                    loss_part=self.loss_part, correct_part=self.correct_part, post_part=self.post_part)
@@ -148,9 +162,12 @@ class WideMLPProgram(MLPProgram):
         for l, name in enumerate(self.names):
             last = l == L - 1
             ops.gemm_nt(x, self.w_t[l], self.h[l], ops.EPI_FWD, bias=st.var(f"{name}_b"), relu=True,
-                        out_t=self.hl_t if last else self.h_t[l], out_f32=self.hl32 if last else None, m=B)
+                        out_t=self.hl_t if last else self.h_t[l],
+                        out_f32=self.hl32 if last and not self.bf16_head else None, m=B)
             x = self.h[l]
-        if self.is_cuda:
+        if self.bf16_head:
+            ops.head_wide_bf16(self._args[q]["head"])
+        elif self.is_cuda:
             ops.head(self.hl32, st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, B, args=self._args[q]["head"])
         else:
             ops.head(self.hl32, st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, B, self.loss_mode, rows=rows,
@@ -186,7 +203,9 @@ class WideMLPProgram(MLPProgram):
                             mask_t=self.h_t[l - 1], out_t=self.dzc_t[l - 1], m=B)
             if self.grad_ready is not None and not early:
                 self.grad_ready(l)
-        if self.is_cuda:
+        if self.bf16_head:
+            ops.out_wgrad_wide(self._args[q]["wgrad"])
+        elif self.is_cuda:
             ops.wgrad_grouped(self._args[q]["items"], args=self._args[q]["wgrad"])
         else:
             st_ = self.state

@@ -277,6 +277,85 @@ def head(hact, w2, b2, labels, m_total, m_train, loss_mode=LOSS_REFERENCE, rows=
     return args
 
 
+def head_wide_bf16_takes(m: int, hidden: int, classes: int) -> bool:
+    """Shapes of the 16-wave output-layer kernels (``csrc/kernels/head_wide.hip``)."""
+    return m % 8 == 0 and hidden % 8 == 0 and 0 < classes <= 16
+
+
+def build_head_wide_args(h, h_t, w2, b2, labels, m, loss_mode, rows=None, dz2=None, dz1_bf=None, dz1_bf_t=None,
+                         loss_part=None, correct_part=None, post_part=None):
+    """Arguments of ``head_wide_bf16``: ``h`` bf16 [>=m, hidden] and its transpose ``h_t`` [hidden, >=m] as the forward
+    product wrote them; every one of the ``m`` rows is a training row."""
+    hd, c = w2.shape
+    if not head_wide_bf16_takes(m, hd, c):
+        raise ValueError("head_wide_bf16: m and hidden must be multiples of 8, at most 16 classes")
+    for name, t, shp in (("h", h, (m, hd)), ("h_t", h_t, (hd, m))):
+        if t.dtype != torch.bfloat16 or t.shape[0] < shp[0] or t.shape[1] < shp[1] or t.stride(1) != 1 or t.stride(0) % 8:
+            raise ValueError(f"head_wide_bf16: {name} must be bf16 [>={shp[0]}, >={shp[1]}], row-major, rows 16-byte aligned")
+    if h.shape[1] != hd or h_t.shape[0] != hd:
+        raise ValueError("head_wide_bf16: activation / weight shape mismatch")
+    nblk = (m + 15) // 16
+    for name, t in (("loss_part", loss_part), ("correct_part", correct_part), ("post_part", post_part)):
+        if t is not None and t.numel() < nblk:
+            raise ValueError(f"head_wide_bf16: {name} needs {nblk} entries")
+    if rows is not None and rows.numel() < m:
+        raise ValueError("head_wide_bf16: rows too short")
+    if rows is None and labels.shape[0] < m:
+        raise ValueError("head_wide_bf16: labels too short")
+    if labels.shape[1] != c:
+        raise ValueError("head_wide_bf16: labels width mismatch")
+    if dz2 is not None and (dz2.dtype != torch.float32 or dz2.shape[0] < m or dz2.shape[1] != 16 or not dz2.is_contiguous()):
+        raise ValueError("head_wide_bf16: dz2 must be float32 [>=m, 16] contiguous")
+    if dz1_bf is not None and (dz1_bf.dtype != torch.bfloat16 or dz1_bf.shape[0] < m or dz1_bf.shape[1] != hd
+                               or dz1_bf.stride(1) != 1):
+        raise ValueError("head_wide_bf16: dz1_bf must be bf16 [>=m, hidden], row-major")
+    if dz1_bf_t is not None and (dz1_bf is None or dz1_bf_t.dtype != torch.bfloat16 or dz1_bf_t.shape[0] != hd
+                                 or dz1_bf_t.shape[1] < m or dz1_bf_t.stride(1) != 1):
+        raise ValueError("head_wide_bf16: dz1_bf_t must be bf16 [hidden, >=m], row-major, next to dz1_bf")
+    _same_device(h, h_t, w2, b2, labels, rows, dz2, dz1_bf, dz1_bf_t, loss_part, correct_part, post_part)
+    return _lib.HeadWideArgs(H=h.data_ptr(), Ht=h_t.data_ptr(), W2=_f32c(w2, "w2").data_ptr(), b2=_f32c(b2, "b2").data_ptr(),
+                             labels=_f32c(labels, "labels").data_ptr(),
+                             rows=_lib.ptr(None if rows is None else _i32c(rows, "rows")), dz2=_lib.ptr(dz2),
+                             dz1_bf=_lib.ptr(dz1_bf), dz1_bf_t=_lib.ptr(dz1_bf_t), loss_part=_lib.ptr(loss_part),
+                             correct_part=_lib.ptr(correct_part), post_part=_lib.ptr(post_part), M=m, Hd=hd, C=c,
+                             ldh=h.stride(0), ldht=h_t.stride(0), ld_bf=0 if dz1_bf is None else dz1_bf.stride(0),
+                             ld_bf_t=0 if dz1_bf_t is None else dz1_bf_t.stride(0), loss_mode=loss_mode, inv_b=1.0 / m,
+                             pad_=0)
+
+
+def head_wide_bf16(args):
+    """Output layer of a wide bf16 network on the GPU: logits, (double-)softmax cross-entropy, accuracy count, dz2 and
+    the masked dz of the last hidden layer (bf16, row-major + transposed), reading the bf16 activation and its
+    transpose (distributed.py:81-87 of the reference)."""
+    _lib.check(_lib.kernels().dtf_head_wide(C.byref(args), _lib.stream_handle()), "head_wide_bf16")
+    return args
+
+
+def build_out_wgrad_wide_args(h_t, dz2, dw, db, batch, tail=None):
+    hd, c = dw.shape
+    if h_t.dtype != torch.bfloat16 or h_t.shape[0] != hd or h_t.shape[1] < batch or h_t.stride(1) != 1 or h_t.stride(0) % 8:
+        raise ValueError("out_wgrad_wide: h_t must be bf16 [hidden, >=batch], row-major, rows 16-byte aligned")
+    if batch % 8 or not 0 < c <= 16:
+        raise ValueError("out_wgrad_wide: batch must be a multiple of 8, at most 16 classes")
+    if dz2.dtype != torch.float32 or dz2.shape[0] < batch or dz2.shape[1] != 16 or not dz2.is_contiguous():
+        raise ValueError("out_wgrad_wide: dz2 must be float32 [>=batch, 16] contiguous")
+    if dw.dtype != torch.float32 or dw.stride(1) != 1 or db.dtype != torch.float32 or db.numel() != c:
+        raise ValueError("out_wgrad_wide: dw [hidden, classes] and db [classes] must be float32")
+    _same_device(h_t, dz2, dw, db)
+    args = _lib.OutWgradWideArgs(Ht=h_t.data_ptr(), dz2=dz2.data_ptr(), dW=dw.data_ptr(), db=db.data_ptr(), Hd=hd, C=c,
+                                 B=batch, ldht=h_t.stride(0), ldw=dw.stride(0), pad_=0)
+    if tail is not None:
+        args.tail = tail
+    return args
+
+
+def out_wgrad_wide(args):
+    """``dw = h^T dz2``, ``db = colsum(dz2)`` of the output layer from the transposed bf16 activation, and the step
+    tail when the arguments carry one."""
+    _lib.check(_lib.kernels().dtf_out_wgrad_wide(C.byref(args), _lib.stream_handle()), "out_wgrad_wide")
+    return args
+
+
 def _head_wide(hact, w2, b2, labels, m_total, m_train, loss_mode, rows, dz2, dz1, probs, loss_part, correct_part, post_part,
                dz1_bf, dz1_bf_t):
     """The last layer with more than 16 classes (beyond the one-workgroup head kernel): logits by the small GEMM,

@@ -65,6 +65,20 @@ class HeadArgs(C.Structure):
                 ("dz1_bf_t", C.c_void_p), ("ld_bf", C.c_int), ("ld_bf_t", C.c_int)]
 
 
+class HeadWideArgs(C.Structure):
+    _fields_ = [("H", C.c_void_p), ("Ht", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("labels", C.c_void_p),
+                ("rows", C.c_void_p), ("dz2", C.c_void_p), ("dz1_bf", C.c_void_p), ("dz1_bf_t", C.c_void_p),
+                ("loss_part", C.c_void_p), ("correct_part", C.c_void_p), ("post_part", C.c_void_p), ("M", C.c_int),
+                ("Hd", C.c_int), ("C", C.c_int), ("ldh", C.c_int), ("ldht", C.c_int), ("ld_bf", C.c_int),
+                ("ld_bf_t", C.c_int), ("loss_mode", C.c_int), ("inv_b", C.c_float), ("pad_", C.c_int)]
+
+
+class OutWgradWideArgs(C.Structure):
+    _fields_ = [("Ht", C.c_void_p), ("dz2", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("Hd", C.c_int),
+                ("C", C.c_int), ("B", C.c_int), ("ldht", C.c_int), ("ldw", C.c_int), ("pad_", C.c_int),
+                ("tail", TailArgs)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("Ct", C.c_void_p), ("C32", C.c_void_p),
                 ("bias", C.c_void_p), ("mask", C.c_void_p), ("bias_out", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
@@ -198,6 +212,10 @@ def _declare_kernels(lib):
     lib.dtf_softmax_xent_blocks.argtypes = [i32]
     lib.dtf_softmax_xent_blocks.restype = i32
     lib.dtf_gather_cast_transpose.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.dtf_head_wide.argtypes = [C.POINTER(HeadWideArgs), vp]
+    lib.dtf_head_wide.restype = i32
+    lib.dtf_out_wgrad_wide.argtypes = [C.POINTER(OutWgradWideArgs), vp]
+    lib.dtf_out_wgrad_wide.restype = i32
     for name in ("dtf_small_gemm", "dtf_wgrad_grouped", "dtf_head", "dtf_step_tail", "dtf_sgd_apply", "dtf_adam_apply",
                  "dtf_truncated_normal", "dtf_accumulate", "dtf_kernels_abi_version", "dtf_gemm_tiled",
                  "dtf_gather_cast_transpose", "dtf_run_schedule", "dtf_mlp2_fwd", "dtf_mlp2_bwd"):

@@ -116,3 +116,49 @@ def test_gpu_folded_layers_pick_up_restored_weights():
     torch.cuda.synchronize()
     rec = prog.read_log(3, 1)[0]
     assert abs(rec.loss - 2.302585) < 1e-3                   # log(10): the stale bf16 copies would give another loss
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss_mode", [0, 1])
+@pytest.mark.parametrize("m,hd,c", [(64, 1024, 10), (40, 264, 7)])
+def test_gpu_bf16_output_layer_kernels_against_fp32_reference(m, hd, c, loss_mode):
+    """head_wide_bf16 / out_wgrad_wide (16-wave kernels reading the bf16 activation and its transpose) against the
+    plain PyTorch mathematics of ops/reference.py on the same (bf16-rounded) activation, ragged shapes included."""
+    from distributed_tensorflow_amd import ops
+    from distributed_tensorflow_amd.ops import reference
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    h = torch.relu(torch.randn(m, hd, generator=g)).to(torch.bfloat16)
+    w2, b2 = torch.randn(hd, c, generator=g) * 0.05, torch.randn(c, generator=g) * 0.1
+    nlab = 2 * m
+    labels = torch.zeros(nlab, c)
+    labels[torch.arange(nlab), torch.randint(0, c, (nlab,), generator=g)] = 1.0
+    rows = torch.randperm(nlab, generator=g)[:m].to(torch.int32)
+    ref = reference.head(h.float(), w2, b2, labels, m, loss_mode, rows, want_dz1=True)
+    hd_ = h.to(dev)
+    ht = torch.zeros(hd, m + 8, dtype=torch.bfloat16, device=dev)          # wider than needed: ld != m
+    ht[:, :m] = hd_.t()
+    dz2 = torch.full((m, 16), 7.0, device=dev)
+    dz1 = torch.zeros(m, hd, dtype=torch.bfloat16, device=dev)
+    dz1_t = torch.zeros(hd, m + 8, dtype=torch.bfloat16, device=dev)
+    nblk = (m + 15) // 16
+    lp, cp, pp = torch.zeros(nblk, device=dev), torch.zeros(nblk, dtype=torch.int32, device=dev), torch.ones(nblk, dtype=torch.int32, device=dev)
+    args = ops.build_head_wide_args(hd_, ht, w2.to(dev), b2.to(dev), labels.to(dev), m, loss_mode, rows=rows.to(dev), dz2=dz2,
+                                    dz1_bf=dz1, dz1_bf_t=dz1_t, loss_part=lp, correct_part=cp, post_part=pp)
+    ops.head_wide_bf16(args)
+    torch.cuda.synchronize()
+    assert abs(float(lp.sum()) - float(ref["loss_sum"])) <= 1e-4 * max(1.0, abs(float(ref["loss_sum"])))
+    assert int(cp.sum()) == int(ref["correct"]) and int(pp.sum()) == 0
+    assert torch.allclose(dz2[:, :c].cpu(), ref["dz2"], rtol=1e-4, atol=1e-7) and float(dz2[:, c:].abs().sum()) == 0.0
+    want = ref["dz1"].to(torch.bfloat16).float()
+    got = dz1.float().cpu()
+    assert torch.allclose(got, want, rtol=2e-2, atol=1e-6)
+    assert torch.equal((got != 0), (want != 0)) or float(((got != 0) != (want != 0)).float().mean()) < 1e-3
+    assert torch.equal(dz1_t[:, :m].cpu(), dz1.t().cpu()) and float(dz1_t[:, m:].abs().sum()) == 0.0
+    # output-layer weight gradient from the transposed activation
+    dw, db = torch.zeros(hd, c, device=dev), torch.zeros(c, device=dev)
+    ops.out_wgrad_wide(ops.build_out_wgrad_wide_args(ht, dz2, dw, db, m))
+    torch.cuda.synchronize()
+    dz2c = dz2[:, :c].cpu()
+    assert torch.allclose(dw.cpu(), h.float().t() @ dz2c, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(db.cpu(), dz2c.sum(0), rtol=1e-4, atol=1e-7)
