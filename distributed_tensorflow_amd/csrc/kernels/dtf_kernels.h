@@ -275,6 +275,14 @@ struct DtfGemmArgs {
   int opt_step_offset;
   int ldwt;
   float opt_lr, opt_b1, opt_b2, opt_eps;
+  // Split-K weight gradient (8-wave kernel, plain EPI_WGRAD): a product whose 256x256 tiles would fill a fraction of
+  // the chip (M = 784: 64 tiles) runs as ksplit x tiles workgroups, each over 1/ksplit of K; partial results go to
+  // split_ws [ksplit][M][ldc] (and split_bias_ws [ksplit][N]) and a second launch sums them in split order into C
+  // (bias_out), so the result does not depend on the order in which workgroups finish.
+  int ksplit;             // 0 or 1 = off
+  int pad2_;
+  float* split_ws;
+  float* split_bias_ws;   // needed when bias_out is given
 };
 
 // A pre-validated launch sequence: the hand-scheduled step (what a graph partitioner + executor do

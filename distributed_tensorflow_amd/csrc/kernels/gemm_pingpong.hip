@@ -65,7 +65,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
   // M and N need not be multiples of 256: operand rows past the end are read out of range (zeros) or belong to a
   // larger buffer (finite or not, they only feed output rows/columns that are never stored), the epilogue guards
   const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 255) >> 8;
-  const int wg = dtf_xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  // split-K (plain weight gradient only): workgroups [s * tiles, (s + 1) * tiles) take K range s
+  const int ntile = tiles_m * tiles_n;
+  const int split = (EPI == EPI_WGRAD && p.ksplit > 1) ? (int)blockIdx.x / ntile : 0;
+  const int kper = (EPI == EPI_WGRAD && p.ksplit > 1) ? (((p.K + p.ksplit - 1) / p.ksplit + 127) & ~127) : p.K;
+  const int k_begin = split * kper;
+  const int k_len = min(p.K - k_begin, kper);          // <= 0 for a split past the end: every load is out of range
+  const int wg = dtf_xcd_remap((int)blockIdx.x - split * ntile, ntile);
   // consecutive (remapped) ids walk down a band of 8 row-tiles: the A panels and one B panel stay in that XCD's L2
   const int band = 8;
   const int per_band = band * tiles_n;
@@ -86,14 +92,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
   unsigned a_vo[2], b_vo[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    a_vo[j] = (unsigned)(m0 + j * 128 + wave * 8 + srow) * (unsigned)p.lda * 2u + kchunk;
-    b_vo[j] = (unsigned)(n0 + (2 * j + (wave >> 2)) * 64 + (wave & 3) * 8 + srow) * (unsigned)p.ldb * 2u + kchunk;
+    a_vo[j] = (unsigned)(m0 + j * 128 + wave * 8 + srow) * (unsigned)p.lda * 2u + kchunk + (unsigned)k_begin * 2u;
+    b_vo[j] = (unsigned)(n0 + (2 * j + (wave >> 2)) * 64 + (wave & 3) * 8 + srow) * (unsigned)p.ldb * 2u + kchunk + (unsigned)k_begin * 2u;
   }
   const unsigned a_half = 64u * (unsigned)p.lda * 2u, b_half = 32u * (unsigned)p.ldb * 2u;
   // K-tiles: an even number that covers K; 16-byte chunks at or past K are requested out of range (the range check
   // of the buffer load then delivers zeros), so K only has to be a multiple of 8
-  const int nk = ((p.K + 127) >> 7) << 1;
-  const int klim = p.K * 2 - (int)kchunk;            // a lane's chunk of K-tile kt is inside K iff kt*128 < klim
+  const int nk = ((max(k_len, 0) + 127) >> 7) << 1;
+  const int klim = k_len * 2 - (int)kchunk;          // a lane's chunk of K-tile kt is inside its K range iff kt*128 < klim
   lds_byte_t* const lds3 = (lds_byte_t*)(lds) + wave * 1024;
 
   auto stage = [&](int buf, int region, int kt) {
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
   unsigned char* const wl = lds + wave * 16384;
   const int crow = m0 + wr * 128, ccol = n0 + wc * 64;          // origin of this wave's block
   if (EPI == EPI_WGRAD || EPI == EPI_WGRAD_OPT) {
-    float* __restrict__ Cf = static_cast<float*>(p.C);
+    float* __restrict__ Cf = (EPI == EPI_WGRAD && p.ksplit > 1) ? p.split_ws + (size_t)split * p.M * p.ldc : static_cast<float*>(p.C);
     // optimizer folded into the epilogue: the same arithmetic as optim.hip (adam_one / sgd), element for element
     constexpr bool opt = EPI == EPI_WGRAD_OPT;
     const bool adam = p.opt_m != nullptr;
@@ -414,7 +420,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
         float s = bias_grad[hb][j];
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (g == 0 && n0 + wc * 64 + hb * 32 + 16 * j + fr < p.N) p.bias_out[n0 + wc * 64 + hb * 32 + 16 * j + fr] = s;
+        float* const bo = (EPI == EPI_WGRAD && p.ksplit > 1) ? p.split_bias_ws + (size_t)split * p.N : p.bias_out;
+        if (g == 0 && n0 + wc * 64 + hb * 32 + 16 * j + fr < p.N) bo[n0 + wc * 64 + hb * 32 + 16 * j + fr] = s;
       }
   }
 }
@@ -422,8 +429,33 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
 // Shapes this kernel takes: bf16, M, N and K multiples of 8 (16-byte chunks of operands and outputs), K at least
 // 256, the transposed mask for the backward epilogue, outputs that take 16-byte stores.  Whether it PAYS (enough
 // 256x256 blocks to fill the chip, little waste at ragged edges) is the caller's decision.
+// dst[i] = sum over the splits, in split order, of the partial weight gradients (ld = ldc: M * ldc floats per split,
+// a multiple of 4) and partial bias gradients
+__global__ __launch_bounds__(256) void splitk_sum_kernel(float* __restrict__ dst, const float* __restrict__ ws, long n4, long stride,
+                                                         float* __restrict__ bias_dst, const float* __restrict__ bias_ws, int N, int S) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    f32x4 acc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ws) + i);
+    for (int s = 1; s < S; ++s) {
+      const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ws + (size_t)s * stride) + i);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    reinterpret_cast<f32x4*>(dst)[i] = acc;
+  } else if (bias_dst && i - n4 < N) {
+    const int c = (int)(i - n4);
+    float acc = bias_ws[c];
+    for (int s = 1; s < S; ++s) acc += bias_ws[(size_t)s * N + c];
+    bias_dst[c] = acc;
+  }
+}
+
 bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a) {
   if (a.dtype != 1 || (a.M & 7) || (a.N & 7) || (a.K & 7) || a.K < 256) return false;
+  if (a.ksplit > 1) {
+    if (a.epilogue != EPI_WGRAD || a.opt_p || !a.split_ws || (a.bias_out && !a.split_bias_ws)) return false;
+    if (a.ksplit > 16 || a.K / a.ksplit < 256 || (reinterpret_cast<uintptr_t>(a.split_ws) & 15)) return false;
+    if (a.ldc != a.N) return false;           // the summing pass treats C and each partial as M * N contiguous floats
+  }
   if (a.epilogue == EPI_BWD && (!a.maskT || (a.ldmaskt & 3))) return false;
   if ((reinterpret_cast<uintptr_t>(a.C) & 15) || (a.ldc & (a.epilogue == EPI_WGRAD ? 3 : 7))) return false;
   if (a.Ct && ((a.ldct & 7) || (reinterpret_cast<uintptr_t>(a.Ct) & 15))) return false;
@@ -439,7 +471,8 @@ bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a) {
 
 int dtf_gemm_pingpong_launch(const DtfGemmArgs& a, hipStream_t s) {
   if (!dtf_gemm_pingpong_takes(a)) return DTF_ERR_SHAPE;
-  dim3 grid(((a.M + 255) >> 8) * ((a.N + 255) >> 8)), block(512);
+  const int split = a.ksplit > 1 ? a.ksplit : 1;
+  dim3 grid(((a.M + 255) >> 8) * ((a.N + 255) >> 8) * split), block(512);
   switch (a.epilogue) {
     case EPI_FWD: hipLaunchKernelGGL(gemm_pp_kernel<EPI_FWD>, grid, block, 0, s, a); break;
     case EPI_BWD: hipLaunchKernelGGL(gemm_pp_kernel<EPI_BWD>, grid, block, 0, s, a); break;
@@ -448,6 +481,12 @@ int dtf_gemm_pingpong_launch(const DtfGemmArgs& a, hipStream_t s) {
       else hipLaunchKernelGGL(gemm_pp_kernel<EPI_WGRAD>, grid, block, 0, s, a);
       break;
     default: return DTF_ERR_ARG;
+  }
+  if (split > 1) {
+    const long n4 = (long)a.M * a.ldc / 4;
+    const long threads = n4 + (a.bias_out ? a.N : 0);
+    hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, static_cast<float*>(a.C),
+                       a.split_ws, n4, (long)a.M * a.ldc, a.bias_out, a.split_bias_ws, a.N, split);
   }
   return dtf_check_launch();
 }

@@ -338,7 +338,7 @@ static int launch_tiled(const DtfGemmArgs& a, hipStream_t s) {
     const char* e = getenv("DTF_GEMM_PINGPONG");
     g_pingpong_mode = e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)) : 2;
   }
-  if (a.opt_p)      // the folded optimizer exists in the 8-wave kernel only: the caller asked for exactly that
+  if (a.opt_p || a.ksplit > 1)      // folded optimizer, split-K: 8-wave kernel only, and the caller asked for exactly that
     return (sizeof(T) == 2 && dtf_gemm_pingpong_takes(a)) ? dtf_gemm_pingpong_launch(a, s) : (int)DTF_ERR_SHAPE;
   if (sizeof(T) == 2 && g_pingpong_mode && dtf_gemm_pingpong_takes(a) && (g_pingpong_mode == 1 || fits))
     return dtf_gemm_pingpong_launch(a, s);

@@ -14,6 +14,11 @@
 // chunks in the dz phase.  The 4-wave kernels of mlp_small.hip, built for the 100-unit reference layer, need 8
 // passes per phase on this shape and read the activation as fp32.
 //
+// Measured at batch 4096 x 4096 hidden units (tools/head_wide_probe.py): head 44 us with operands in the caches, 70 us
+// behind a 256 MB write (the 4-wave fp32 kernel: 60 / 70); logits + loss part 17 us, the dz part 27 us, of which the
+// accesses to the TRANSPOSED tensors (mask from H^T, dz^T out: 32-byte pieces of 128-byte lines, because a workgroup
+// owns only 16 batch rows) are 9 us warm and 28 us cold.  Weight gradient 12 us warm / 20 us cold.
+//
 // Workgroup ids are remapped so that consecutive row blocks run on the same XCD: four of them share every 128-byte
 // line of H^T (64 batch rows of one hidden unit) and of the transposed dz output.
 #include "dtf_device.h"
@@ -44,6 +49,17 @@ __global__ __launch_bounds__(NW * 64) void head_wide_kernel(DtfHeadWideArgs p) {
   const rsrc_t rht = make_rsrc(p.Ht, (unsigned)(((size_t)(Hd - 1) * p.ldht + M) * 2u));
   const rsrc_t rw = make_rsrc(p.W2, (unsigned)Hd * (unsigned)C * 4u);
 
+  // what phase B needs from memory is requested before phase A (the label row is a dependent load): it has arrived by
+  // the time the logits are complete
+  const int brow = r0 + 4 * g + wave;                   // the row this lane group handles in phase B (waves 0..3)
+  const bool brow_ok = wave < 4 && brow < M;
+  float labv = 0.f, biasv = 0.f;
+  if (wave < 4) {
+    const int lrow = p.rows ? p.rows[brow_ok ? brow : 0] : brow;
+    labv = p.labels[(size_t)(brow_ok ? lrow : 0) * C + (cls_ok ? fr : 0)];
+    biasv = p.b2[cls_ok ? fr : 0];
+  }
+
   // ---- phase A: partial logits of rows r0..r0+15 over this wave's sixteenth of the hidden units.  MFMA k-slice j of
   //      a 32-unit chunk pairs A[row fr][k0 + 8g + j] with W2[k0 + 8g + j][class fr]: a lane's eight activations are
   //      one 16-byte load.
@@ -55,7 +71,7 @@ __global__ __launch_bounds__(NW * 64) void head_wide_kernel(DtfHeadWideArgs p) {
     const bool arow_ok = arow < M;
     const unsigned a_row_off = (unsigned)arow * (unsigned)p.ldh * 2u;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int CH = 4;
+    constexpr int CH = 8;                                // 4096 hidden units: one pass per wave
     for (int cb = c_lo; cb < c_hi; cb += CH) {
       u32x4_t hv[CH];
       float bv[CH][8];
@@ -82,12 +98,9 @@ __global__ __launch_bounds__(NW * 64) void head_wide_kernel(DtfHeadWideArgs p) {
 
   // ---- phase B: waves 0..3; wave w does the softmax / loss / accuracy / dz2 math of rows 4g + w ----
   if (wave < 4) {
-    const int row = r0 + 4 * g + wave;
-    const bool row_ok = row < M;
-    const int lrow = p.rows ? p.rows[row_ok ? row : 0] : row;
-    const float labv = p.labels[(size_t)(row_ok ? lrow : 0) * C + (cls_ok ? fr : 0)];
+    const int row = brow;
+    const bool row_ok = brow_ok;
     const float lab = (row_ok && cls_ok) ? labv : 0.f;
-    const float biasv = p.b2[cls_ok ? fr : 0];
     float zsum = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) zsum += red[w][wave][lane];       // fixed order: reproducible logits
@@ -206,14 +219,55 @@ DTF_EXPORT int dtf_head_wide(const DtfHeadWideArgs* a, hipStream_t s) {
   return dtf_check_launch();
 }
 
+// Step tail for a large batch.  dtf_tail_body gives the indices of the next batch to 256 threads, each with a 64-bit
+// division and two dependent loads per index: 16 serial rounds for 4096 rows, which made this one workgroup the longest
+// of its launch.  Here every wave of the workgroup takes a share of the indices first (one 64-bit division per thread
+// for the start of the batch, 32-bit arithmetic per index, the loads of a thread's indices all in flight), then waves
+// 4.. end and the first 256 threads do the reduction and the counters exactly as dtf_tail_body does (a barrier does
+// not wait for waves that have ended).
+__device__ __forceinline__ void tail_wide(const DtfTailArgs& t, int tid, int nthreads) {
+  const int ls = t.state[1];
+  __syncthreads();                                    // every thread holds the counter before thread 0 advances it
+  if (t.ridx_next) {
+    const long long base = (long long)(ls + 1) * t.B;
+    const long long epoch0 = base / t.n_train;
+    const unsigned pos0 = (unsigned)(base - epoch0 * t.n_train);
+    constexpr int U = 4;
+    for (int i0 = tid; i0 < t.B; i0 += U * nthreads) {
+      int row[U], prev[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * nthreads;
+        const bool ok = i < t.B;
+        const unsigned s = pos0 + (unsigned)(ok ? i : 0);           // < 2^32: both terms are below 2^31
+        const unsigned wrap = s / (unsigned)t.n_train;
+        const int pos = (int)(s - wrap * (unsigned)t.n_train);
+        row[u] = t.perm ? t.perm[(size_t)((epoch0 + wrap) & 1) * t.n_train + pos] : pos;
+        prev[u] = t.ridx_cur ? t.ridx_cur[ok ? i : 0] : row[u];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * nthreads;
+        if (i < t.B) {
+          t.ridx_next[t.B + i] = prev[u];             // the batch just trained on becomes the accuracy-only rows
+          t.ridx_next[i] = row[u];
+        }
+      }
+    }
+  }
+  if (tid >= 256) return;
+  DtfTailArgs r = t;
+  r.ridx_next = nullptr;
+  dtf_tail_body(r, tid, 256, false);
+}
+
 // dW2[Hd, C] = H^T[Hd, B] . dz2[B, 16],  db2 = colsum(dz2).  One workgroup = 16 hidden units; its 16 waves take
 // contiguous sixteenths of the batch and their partial tiles are summed through LDS in wave order.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void out_wgrad_wide_kernel(DtfOutWgradWideArgs p) {
   const int ntile = (p.Hd + 15) >> 4;
   if ((int)blockIdx.x >= ntile) {
-    if (threadIdx.x >= 256) return;                  // the step tail is written for exactly 256 threads
-    if (p.tail.enable) dtf_tail_body(p.tail, threadIdx.x, 256, false);
+    if (p.tail.enable) tail_wide(p.tail, threadIdx.x, NW * 64);
     return;
   }
   __shared__ float part[NW][5][64];

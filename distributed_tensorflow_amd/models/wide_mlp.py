@@ -58,6 +58,13 @@ class WideMLPProgram(MLPProgram):
         self.refresh_compute_copies()
         self.grad_ready = None              # engine hook: called with a bucket index of grad_groups()
         self.folded = [False] * len(hidden)  # layers whose weight-gradient epilogue applies the optimizer itself
+        # weight-gradient products whose tiles would fill a fraction of the chip (first layer: 784 inputs) run split-K
+        self.split_k = [None] * len(hidden)
+        if self.is_cuda and T == torch.bfloat16 and os.environ.get("DTF_SPLIT_K", "1") != "0":
+            for l in range(len(hidden)):
+                s = ops.split_k_for(dims[l], dims[l + 1], B)
+                if s > 1:
+                    self.split_k[l] = ops.SplitK(s, dims[l], dims[l + 1], dev)
         # bf16 on the GPU: the output layer's kernels read the bf16 activation and its transpose as the last forward
         # product wrote them (16-wave kernels of csrc/kernels/head_wide.hip); otherwise the fp32 copy and the 4-wave
         # kernels shared with the reference model.  DTF_WIDE_HEAD=0 selects the latter for comparison.
@@ -195,7 +202,7 @@ class WideMLPProgram(MLPProgram):
                             opt=opt)            # refreshes W_l and W_l^T (compute dtype) itself
                 continue
             ops.gemm_nt(a_t, self.dzc_t[l], st.grad(wname), ops.EPI_WGRAD,
-                        bias_out=st.grad(f"{self.names[l]}_b"))
+                        bias_out=st.grad(f"{self.names[l]}_b"), split_k=self.split_k[l])
             if early:
                 self.grad_ready(l)
             if l > 0:

@@ -677,8 +677,30 @@ def gemm_pingpong_takes(M: int, N: int, K: int) -> bool:
     return M % 8 == 0 and N % 8 == 0 and K % 8 == 0 and K >= 256
 
 
+class SplitK:
+    """Workspace of a split-K weight-gradient product: ``splits`` partial results [splits, M, N] fp32 (and partial
+    bias gradients [splits, N]), summed in split order by a second launch."""
+
+    def __init__(self, splits: int, m: int, n: int, device):
+        self.splits = int(splits)
+        self.ws = torch.empty((self.splits, m, n), dtype=torch.float32, device=device)
+        self.bias_ws = torch.empty((self.splits, n), dtype=torch.float32, device=device)
+
+
+def split_k_for(M: int, N: int, K: int) -> int:
+    """How many K ranges a weight-gradient product should be cut into so that its 256x256 tiles fill the 256 CUs
+    (1 = leave it alone): 784 x 4096 is 64 tiles -> 4."""
+    tiles = -(-M // 256) * -(-N // 256)
+    if not gemm_pingpong_takes(M, N, K) or tiles >= 128:
+        return 1
+    s = min(16, 256 // tiles)
+    while s > 1 and K // s < 1024:
+        s -= 1
+    return s
+
+
 def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t=None, out_f32=None, bias_out=None,
-            m=None, mask_t=None, opt=None):
+            m=None, mask_t=None, opt=None, split_k=None):
     """``out[:m] = epilogue(a[:m] @ b^T)`` with ``a`` [M,K] and ``b`` [N,K], both k-contiguous.
 
     forward: ``+bias``, ReLU, optional transposed copy ``out_t`` [N,M] and fp32 copy ``out_f32``;
@@ -686,7 +708,8 @@ def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t
     when given), optional ``out_t``;
     weight gradient: ``out`` is fp32, ``bias_out[n] = sum_k b[n,k]``; with ``opt`` (a ``FoldedOptimizer``) the
     gradient is not stored: the epilogue updates ``opt.p`` (and moments) and refreshes ``opt.w`` (bf16, 8-wave
-    kernel only; the call fails if the shape is outside that kernel's range).
+    kernel only; the call fails if the shape is outside that kernel's range); with ``split_k`` (a ``SplitK``) the
+    product runs as that many K ranges per tile and a summing pass (bf16, 8-wave kernel, ``out`` contiguous).
     """
     M = m if m is not None else a.shape[0]
     N, K = b.shape
@@ -751,6 +774,14 @@ def gemm_nt(a, b, out, epilogue=EPI_FWD, bias=None, relu=False, mask=None, out_t
                          relu=int(bool(relu)), epilogue=epilogue, dtype=_dtype_code(a), a_bytes=_lib.span_bytes(a),
                          b_bytes=_lib.span_bytes(b), maskT=_lib.ptr(mask_t), ldmaskt=0 if mask_t is None else mask_t.stride(0),
                          pad_=0)
+    if split_k is not None and split_k.splits > 1:
+        if epilogue != EPI_WGRAD or opt is not None or a.dtype != torch.bfloat16 or M != a.shape[0]:
+            raise ValueError("gemm_nt: split-K belongs to a plain bf16 weight-gradient product")
+        if tuple(split_k.ws.shape) != (split_k.splits, M, N) or tuple(split_k.bias_ws.shape) != (split_k.splits, N) \
+                or out.stride(0) != N:
+            raise ValueError("gemm_nt: split-K workspace must be [splits, M, N] / [splits, N] and out contiguous")
+        _same_device(a, split_k.ws, split_k.bias_ws)
+        args.ksplit, args.split_ws, args.split_bias_ws = split_k.splits, split_k.ws.data_ptr(), split_k.bias_ws.data_ptr()
     if opt is not None:
         if epilogue != EPI_WGRAD or a.dtype != torch.bfloat16 or M != a.shape[0]:
             raise ValueError("gemm_nt: the folded optimizer belongs to a bf16 weight-gradient product")

@@ -87,7 +87,8 @@ class GemmArgs(C.Structure):
                 ("b_bytes", C.c_uint), ("maskT", C.c_void_p), ("ldmaskt", C.c_int), ("pad_", C.c_int),
                 ("opt_p", C.c_void_p), ("opt_m", C.c_void_p), ("opt_v", C.c_void_p), ("opt_w", C.c_void_p),
                 ("opt_wt", C.c_void_p), ("opt_step", C.c_void_p), ("opt_step_offset", C.c_int), ("ldwt", C.c_int),
-                ("opt_lr", C.c_float), ("opt_b1", C.c_float), ("opt_b2", C.c_float), ("opt_eps", C.c_float)]
+                ("opt_lr", C.c_float), ("opt_b1", C.c_float), ("opt_b2", C.c_float), ("opt_eps", C.c_float),
+                ("ksplit", C.c_int), ("pad2_", C.c_int), ("split_ws", C.c_void_p), ("split_bias_ws", C.c_void_p)]
 
 
 WLOG_INTS = 64

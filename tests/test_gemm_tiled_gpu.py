@@ -219,3 +219,21 @@ def test_folded_optimizer_epilogue_against_separate_kernels(pingpong_kernel):
             assert torch.equal(wt[:, :M], pr.to(torch.bfloat16).t()) and float(wt[:, M:].abs().sum()) == 0.0
         if adam:
             assert torch.equal(mf, mr) and torch.equal(vf, vr)
+
+
+@pytest.mark.parametrize("M,N,K,S", [(784, 512, 4096, 4), (264, 520, 1024, 3)])
+def test_split_k_weight_gradient_matches_the_single_pass(pingpong_kernel, M, N, K, S):
+    """Split-K weight gradient (K ranges per tile + summing pass) against the one-pass product and the fp32 reference."""
+    xt, dyt = _rand(M, K, seed=1).to(DEV, torch.bfloat16), _rand(N, K, seed=2, scale=0.1).to(DEV, torch.bfloat16)
+    ref, db_ref = torch.zeros(M, N, device=DEV), torch.zeros(N, device=DEV)
+    ops.gemm_nt(xt, dyt, ref, ops.EPI_WGRAD, bias_out=db_ref)
+    out, db = torch.full((M, N), 3.0, device=DEV), torch.full((N,), 3.0, device=DEV)
+    ops.gemm_nt(xt, dyt, out, ops.EPI_WGRAD, bias_out=db, split_k=ops.SplitK(S, M, N, DEV))
+    torch.cuda.synchronize()
+    want = xt.float() @ dyt.float().t()
+    assert torch.allclose(out, want, rtol=1e-4, atol=1e-3) and torch.allclose(out, ref, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(db, dyt.float().sum(1), rtol=1e-4, atol=1e-3) and torch.allclose(db, db_ref, rtol=1e-5, atol=1e-4)
+    again = torch.zeros(M, N, device=DEV)
+    ops.gemm_nt(xt, dyt, again, ops.EPI_WGRAD, split_k=ops.SplitK(S, M, N, DEV))
+    assert torch.equal(again, out)              # fixed summation order: run-to-run identical
+    assert ops.split_k_for(784, 4096, 4096) == 4 and ops.split_k_for(4096, 4096, 4096) == 1
