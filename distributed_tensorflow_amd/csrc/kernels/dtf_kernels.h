@@ -421,4 +421,5 @@ DTF_EXPORT int dtf_adam_apply(float* param, const float* grad, float* m, float* 
                               hipStream_t s);
 DTF_EXPORT int dtf_truncated_normal(float* out, int64_t n, float stddev, uint64_t seed, uint64_t stream_id, hipStream_t s);
 DTF_EXPORT int dtf_accumulate(float* dst, const float* src, int64_t n, float alpha, float beta, hipStream_t s);
+DTF_EXPORT int dtf_upload_words(void* dst, const void* host_src, int64_t n_words, hipStream_t s);
 DTF_EXPORT int dtf_kernels_abi_version();

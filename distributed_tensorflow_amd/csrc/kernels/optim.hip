@@ -182,6 +182,32 @@ DTF_EXPORT int dtf_accumulate(float* dst, const float* src, int64_t n, float alp
 }
 
 // --------------------------------------------------------------------------------------
+// Upload by kernel: dst (device) = src (page-locked HOST memory, mapped into the device's address space), 4-byte
+// words, read over the host link by the shader cores.  The written data passes through the same caches as any kernel
+// output, so the kernels that read it next are ordered and coherent with it by the ordinary stream rules; used for
+// the resident dataset and the epoch permutations, where a copy-engine upload into a re-used allocation was seen
+// to leave a few stale rows on some machines.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upload_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+DTF_EXPORT int dtf_upload_words(void* dst, const void* host_src, int64_t n_words, hipStream_t s) {
+  if (!dst || !host_src) return DTF_ERR_ARG;
+  if (n_words <= 0) return DTF_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(host_src)) & 3u) return DTF_ERR_ALIGN;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, host_src) != hipSuccess || at.type != hipMemoryTypeHost || at.devicePointer == nullptr) {
+    (void)hipGetLastError();
+    return DTF_ERR_ARG;                              // not page-locked, mapped host memory
+  }
+  hipLaunchKernelGGL(upload_words_kernel, dim3(stream_grid(n_words, 256)), dim3(256), 0, s, static_cast<unsigned*>(dst),
+                     static_cast<const unsigned*>(at.devicePointer), n_words);
+  return dtf_check_launch();
+}
+
+// --------------------------------------------------------------------------------------
 // truncated normal initialiser (tf.truncated_normal, distributed.py:67-72): N(0, stddev)
 // re-sampled until |v| <= 2 stddev.  Counter-based Philox4x32-10, one counter block per
 // (element, attempt) so the result does not depend on the launch geometry.

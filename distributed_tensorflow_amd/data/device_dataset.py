@@ -28,20 +28,35 @@ class DeviceDataset:
         # permutations travel through page-locked staging buffers owned by this object (one per device buffer): the
         # source of the upload then stays valid and in place for as long as the copy engine may be reading it
         self._stage = None
+        self._stage_done = [None, None]       # events: the upload that last read each staging buffer has finished
         if shuffle and self.device.type == "cuda":
             self._stage = torch.zeros((2, self.n), dtype=torch.int32).pin_memory()
 
     def _upload(self, array) -> torch.Tensor:
-        """Host array -> device tensor through a page-locked copy of our own and an explicit wait, not through the
-        runtime's path for pageable memory: on some machines of the pool a split uploaded that way and read by the very
-        next kernels showed a few stale rows (labels still zero, images of another row), never with this path."""
+        """Host array -> device tensor through a page-locked copy of our own, read by a KERNEL over the host link
+        (``ops.upload_from_pinned``), and an explicit wait.  On some machines of the pool a split uploaded by the
+        copy engine into a re-used allocation (pageable or page-locked source alike) and read by the very next kernels
+        showed a few stale rows (labels still zero, images of another row); data written by a kernel is ordered and
+        coherent with the kernels behind it by the ordinary stream rules."""
         t = torch.from_numpy(array)
         if self.device.type != "cuda":
             return t.to(self.device)
-        staged = t.pin_memory()
-        out = torch.empty(t.shape, dtype=t.dtype, device=self.device)
-        out.copy_(staged, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        return self._kernel_upload(torch.empty(t.shape, dtype=t.dtype, device=self.device), t.contiguous().pin_memory())
+
+    def _kernel_upload(self, out: torch.Tensor, staged: torch.Tensor, wait: bool = True):
+        """Returns ``out`` after waiting for the copy, or (``wait=False``) an event that marks its end: the stream is
+        not drained for an epoch's permutation in the middle of a run."""
+        from .. import ops
+        with torch.cuda.device(self.device):
+            if out.element_size() == 4 and ops._lib.kernels_available():
+                ops.upload_from_pinned(out, staged)
+            else:
+                out.copy_(staged, non_blocking=True)
+            if not wait:
+                ev = torch.cuda.Event()
+                ev.record()
+                return ev
+            torch.cuda.current_stream(self.device).synchronize()
         return out
 
     def max_steps_per_launch(self, batch: int) -> int:
@@ -67,10 +82,12 @@ class DeviceDataset:
                 p = torch.from_numpy(epoch_permutation(self.seed, e, self.n))
                 if self._stage is not None:
                     # (the launches that may still read the device buffer precede the copy in stream order; the
-                    # staging buffer of this slot was last used two epochs ago and that copy has long completed)
+                    # staging buffer of this slot was last used two epochs ago: wait for that upload's event)
+                    ev = self._stage_done[e & 1]
+                    if ev is not None:
+                        ev.synchronize()
                     self._stage[e & 1].copy_(p)
-                    self.perm[e & 1].copy_(self._stage[e & 1], non_blocking=True)
-                    torch.cuda.current_stream(self.device).synchronize()
+                    self._stage_done[e & 1] = self._kernel_upload(self.perm[e & 1], self._stage[e & 1], wait=False)
                 else:
                     self.perm[e & 1].copy_(p)
                 self._resident[e & 1] = e

@@ -635,6 +635,21 @@ def accumulate(dst, src, alpha=1.0, beta=1.0):
     return dst
 
 
+def upload_from_pinned(dst, src):
+    """``dst`` (device tensor) = ``src`` (page-locked host tensor of the same dtype and size) copied by a kernel that
+    reads the host memory directly, on the current stream; the caller keeps ``src`` alive and unchanged until the
+    stream has passed the copy."""
+    if not dst.is_cuda or src.is_cuda or not src.is_pinned():
+        raise ValueError("upload_from_pinned: dst on the GPU, src in page-locked host memory")
+    if dst.dtype != src.dtype or dst.numel() != src.numel() or dst.element_size() != 4:
+        raise ValueError("upload_from_pinned: same 4-byte dtype and element count on both sides")
+    if not dst.is_contiguous() or not src.is_contiguous():
+        raise ValueError("upload_from_pinned: contiguous tensors")
+    _lib.check(_lib.kernels().dtf_upload_words(dst.data_ptr(), src.data_ptr(), dst.numel(), _lib.stream_handle()),
+               "upload_from_pinned")
+    return dst
+
+
 def truncated_normal_(out, stddev, seed, stream_id=0):
     """Fill ``out`` with N(0, stddev) truncated at two standard deviations (distributed.py:67-72)."""
     if not out.is_cuda:

@@ -213,6 +213,8 @@ def _declare_kernels(lib):
     lib.dtf_softmax_xent_blocks.argtypes = [i32]
     lib.dtf_softmax_xent_blocks.restype = i32
     lib.dtf_gather_cast_transpose.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.dtf_upload_words.argtypes = [vp, vp, i64, vp]
+    lib.dtf_upload_words.restype = i32
     lib.dtf_head_wide.argtypes = [C.POINTER(HeadWideArgs), vp]
     lib.dtf_head_wide.restype = i32
     lib.dtf_out_wgrad_wide.argtypes = [C.POINTER(OutWgradWideArgs), vp]

@@ -258,3 +258,22 @@ def test_head_writes_bf16_operands_of_the_next_products():
     assert float(bft[:, M:].abs().max()) == 0.0
     with pytest.raises(RuntimeError):
         ops.head(hact, w2, b2, lab, M, M, dz2=dz2b, dz1_bf=bf, dz1_bf_t=torch.zeros(H, 202, dtype=torch.bfloat16, device=DEV))
+
+
+def test_upload_from_pinned_is_a_plain_copy():
+    """Kernel upload from page-locked host memory (the dataset's way onto the GPU): every word arrives; pageable or
+    mis-sized sources are refused."""
+    src = torch.arange(3 * 1000 * 7, dtype=torch.float32).reshape(3000, 7).pin_memory()
+    dst = torch.zeros(3000, 7, device=DEV)
+    ops.upload_from_pinned(dst, src)
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu(), src)
+    isrc = torch.randint(0, 1 << 30, (12345,), dtype=torch.int32).pin_memory()
+    idst = torch.zeros(12345, dtype=torch.int32, device=DEV)
+    ops.upload_from_pinned(idst, isrc)
+    torch.cuda.synchronize()
+    assert torch.equal(idst.cpu(), isrc)
+    with pytest.raises(ValueError):
+        ops.upload_from_pinned(dst, torch.zeros(3000, 7))               # pageable
+    with pytest.raises(ValueError):
+        ops.upload_from_pinned(dst, torch.zeros(10).pin_memory())       # size

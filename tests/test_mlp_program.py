@@ -269,6 +269,35 @@ def test_gpu_two_launch_step_matches_three_launch_step(monkeypatch, hidden, batc
     assert prog_2.post_correct_of_last_step() == prog_3.post_correct_of_last_step()
 
 
+def _first_batch_problems(prog, split, seed):
+    """What is wrong with a started program's view of its first batch (empty list = nothing): the uploaded split, the row
+    indices the step tail wrote, the rows and labels gathered for the two-launch step."""
+    from distributed_tensorflow_amd.data.mnist import epoch_permutation
+    torch.cuda.synchronize()
+    B, q = prog.B, prog.steps_enqueued % prog.P
+    img, lab = torch.from_numpy(split.images), torch.from_numpy(split.labels)
+    want_rows = torch.from_numpy(epoch_permutation(seed, 0, prog.data.n)[:B].astype("int64"))
+    out = []
+    d_img, d_lab = prog.data.images.cpu(), prog.data.labels.cpu()
+    if not torch.equal(d_img, img):
+        out.append(f"uploaded images differ from the host split in rows {(d_img != img).any(1).nonzero().flatten().tolist()[:8]}")
+    if not torch.equal(d_lab, lab):
+        out.append(f"uploaded labels differ from the host split in rows {(d_lab != lab).any(1).nonzero().flatten().tolist()[:8]}")
+    if not torch.equal(prog.data.perm[0].cpu().long(), torch.from_numpy(epoch_permutation(seed, 0, prog.data.n).astype("int64"))):
+        out.append("the resident permutation of epoch 0 differs from the host's")
+    got_rows = prog.ridx[q][:B].cpu().long()
+    if not torch.equal(got_rows, want_rows):
+        out.append(f"row indices of the first batch differ at positions {(got_rows != want_rows).nonzero().flatten().tolist()[:8]}")
+    if prog.fused2:
+        xg = prog.xg[q][:B].cpu()
+        if not torch.equal(xg, img[want_rows]):
+            out.append(f"gathered rows differ at batch positions {(xg != img[want_rows]).any(1).nonzero().flatten().tolist()[:8]}")
+        lg = prog.labg[q][:prog.C, :B].cpu()
+        if not torch.equal(lg, lab[want_rows].t()):
+            out.append(f"gathered labels differ at batch positions {(lg != lab[want_rows].t()).any(0).nonzero().flatten().tolist()[:8]}")
+    return out
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", ["1", "0", "sharded"])
 def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch, fused, one_rank_rccl_group):
@@ -287,12 +316,18 @@ def test_gpu_peer_mapped_update_entry_on_one_rank(monkeypatch, fused, one_rank_r
         st.initialize(seed=11)
         prog = MLPProgram(st, DeviceDataset(ds.train, "cuda", shuffle_seed=5), 100, [100], fused_update=not p2p)
         eng = SyncReplicasEngine(prog, st, collective="all_reduce", force_collectives=p2p)
+        prog.start()
+        problems = _first_batch_problems(prog, ds.train, 5)
+        assert not problems, (p2p, problems)
+        initial.append(st.params.clone())
         eng.run(30, 8)
         torch.cuda.synchronize()
         return st, prog, eng
 
+    initial = []
     st_p, prog_p, eng_p = make(True)
     st_f, prog_f, eng_f = make(False)
+    assert torch.equal(initial[0], initial[1]), "the two programs started from different parameters"
     assert eng_p.p2p is not None and prog_p.after_compute is None and eng_f.p2p is None
     assert eng_p.p2p_fused == (fused != "0") and eng_p.p2p_mode == ("sharded" if fused == "sharded" else "replicated")
     for a, b in zip(prog_p.read_log(0, 30), prog_f.read_log(0, 30)):
