@@ -269,6 +269,17 @@ def test_bench_launch_line_with_two_ranks_sharing_the_gpu(config, expect):
     assert abs(d["value"] - 200 * 120 / (d["ms_per_step"] * 120 / 1e3)) < 1e-6 * d["value"]
 
 
+def test_bench_wide_async_with_adam_on_the_device_side_engine():
+    """`wide_mlp_async` (Adam) on the peer-mapped push/pull engine: the moments live next to the master slice in the
+    owner's exported region, the bf16 products run on the pulled replica; two ranks sharing the GPU."""
+    d = _bench_two_ranks("wide_mlp_async", ["--dtype", "bf16", "--hidden_units", "512", "--batch_size", "256"], 6, 2,
+                         {"DTF_PEER_ASYNC": "1"})
+    c = d["config"]
+    assert c["engine"] == "PeerMappedAsyncEngine" and c["optimizer"] == "adam" and c["mode"] == "async"
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0
+    assert c["staleness_configured"] == 0 and d["staleness_max"] >= 0 and d["global_step"] >= 1 + 2 * 8
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_two_ranks_bucketed_overlap_on_one_gpu(dtype):
     # buckets are processed on a second stream while the backward kernels of the layers below run;
