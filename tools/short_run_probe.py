@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--idle_ms", type=float, default=0.0, help="host sleep before each timed run (GPU clocks fall when idle)")
     ap.add_argument("--launch", default="graph", choices=["graph", "native"],
                     help="graph: replay prepared hipGraphs; native: one native call launches every kernel of the run")
+    ap.add_argument("--first_launch", action="store_true",
+                    help="capture the timed run's graph anew before every repeat: the timed replay is that graph's FIRST launch")
     a = ap.parse_args()
     from distributed_tensorflow_amd import ops
     from distributed_tensorflow_amd.data import mnist
@@ -45,6 +47,8 @@ def main():
         tot, host = [], []
         for _ in range(a.repeats):
             if a.launch == "graph":
+                if a.first_launch:
+                    prog._graphs.clear()
                 prog.prepare_graphs(5, 64)
                 prog.prepare_graphs(n, 64, start_offset=5)
             eng.run(5, 64)
@@ -70,7 +74,7 @@ def main():
     mx, my = sum(xs) / len(xs), sum(ys) / len(ys)
     slope = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / sum((x - mx) ** 2 for x in xs)
     print(json.dumps({"rows": rows, "per_step_us": slope, "fixed_us": my - slope * mx, "idle_ms": a.idle_ms,
-                      "launch": a.launch}, indent=1))
+                      "launch": a.launch, "first_launch": a.first_launch}, indent=1))
 
 
 if __name__ == "__main__":
