@@ -449,8 +449,10 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     bold = __builtin_nontemporal_load(mbptr);
   }
   int seq = 0;
+  bool dead = false;                                // the transport has failed earlier in this run: do not wait again
   if (MODE == 2 || MODE == 4) {
     seq = p.ctr_snap[1] + 1;                        // number of this step, the same on every rank
+    dead = __hip_atomic_load(MODE == 2 ? p.peer.err : p.shard.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     if (tid == 0) *peer_timeout = 0;
   }
   // mode 4: only the rank that owns this workgroup's tiles needs their old values
@@ -554,7 +556,7 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
         // the owner's answer: this workgroup's tiles, updated, in MY outbox
         int* f = reinterpret_cast<int*>(sh.region[me] + sh.outflag_off) + wgid;
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
-          if (__builtin_amdgcn_s_memrealtime() - t0 > sh.timeout_ticks) {
+          if (dead || __builtin_amdgcn_s_memrealtime() - t0 > sh.timeout_ticks) {
             *peer_timeout = 1;
             break;
           }
@@ -583,7 +585,7 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     if (tid < world && tid != me) {
       int* f = reinterpret_cast<int*>(sh.region[me] + sh.inflag_off) + tid * DTF_MLP2_MAX_WG + wgid;
       while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
-        if (__builtin_amdgcn_s_memrealtime() - t0 > sh.timeout_ticks) {
+        if (dead || __builtin_amdgcn_s_memrealtime() - t0 > sh.timeout_ticks) {
           *peer_timeout = 1;
           break;
         }
@@ -666,7 +668,7 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       // step numbers only grow; a wall-clock limit instead of an endless spin
       while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
-        if (__builtin_amdgcn_s_memrealtime() - t0 > p.peer.timeout_ticks) {
+        if (dead || __builtin_amdgcn_s_memrealtime() - t0 > p.peer.timeout_ticks) {
           *peer_timeout = 1;
           break;
         }

@@ -70,10 +70,17 @@ struct P2PKernelArgs {
   unsigned timeout_ticks;         // of the 100 MHz constant clock
 };
 
+// Every wait below gives up at once when the error word is already set: after the first wait of a run has hit its
+// limit, the remaining steps of the same graph (up to 2 x 64 launches) must not each wait that long again.
+__device__ __forceinline__ bool p2p_already_failed(const int* err) {
+  return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
 __global__ __launch_bounds__(256) void p2p_allreduce_sgd_kernel(P2PKernelArgs a) {
   __shared__ int timed_out;
   const int tid = threadIdx.x;
   const int seq = *a.seq_ptr;
+  const bool dead = p2p_already_failed(a.err);
   if (tid == 0) timed_out = 0;
   if (blockIdx.x == 0 && tid < a.world && tid != a.rank)
     __hip_atomic_store(a.flags_peer[tid] + a.slot * kMaxPeers + a.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_sgd_kernel(P2PKernelArgs a)
     int* f = a.flags_local + a.slot * kMaxPeers + tid;
     // step numbers only grow: ">= seq" also accepts a peer that is already one step ahead
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+      if (dead || __builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
         timed_out = 1;
         break;
       }
@@ -261,6 +268,7 @@ __global__ __launch_bounds__(256) void sync_general_kernel(P2PGeneralArgs a) {
   __shared__ int sh_timeout;
   const int tid = threadIdx.x;
   const int seq = *a.seq_ptr;
+  const bool dead = p2p_already_failed(a.err);
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   if (tid == 0) {
     sh_timeout = 0;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void sync_general_kernel(P2PGeneralArgs a) {
             if (v == seq) { mask |= 1 << k; ++count; }
           }
           if (count >= a.need) break;
-          if (p2p_wait_expired(t0, a.timeout_ticks)) { late = true; break; }
+          if (dead || p2p_wait_expired(t0, a.timeout_ticks)) { late = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
         if (!late) {
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(256) void sync_general_kernel(P2PGeneralArgs a) {
     for (;;) {
       const unsigned long long w = __hip_atomic_load(d, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
       if ((int)(w >> 32) == seq) { sh_mask = (int)(w & 0xffffffffu); break; }
-      if (p2p_wait_expired(t0, a.timeout_ticks)) { sh_timeout = 1; break; }
+      if (dead || p2p_wait_expired(t0, a.timeout_ticks)) { sh_timeout = 1; break; }
       __builtin_amdgcn_s_sleep(4);
     }
   }
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(256) void sync_general_kernel(P2PGeneralArgs a) {
     __hip_atomic_store(a.sync_peer[k] + kDoneOff + a.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   for (int k = 0; k < a.world; ++k) {
     while (__hip_atomic_load(a.sync_local + kDoneOff + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq - 2) {
-      if (p2p_wait_expired(t0, a.timeout_ticks)) { *a.err = 1; return; }
+      if (dead || p2p_wait_expired(t0, a.timeout_ticks)) { *a.err = 1; return; }
       __builtin_amdgcn_s_sleep(8);
     }
   }

@@ -9,7 +9,9 @@ Used for the small-model sync step when every rank sits on one node (SGD, all-re
 process group); ``DTF_P2P_ALLREDUCE=0`` keeps RCCL, ``=1`` also allows it on gloo rehearsal groups.  Before
 the engine trusts it, :meth:`P2PAllReduce.self_check` runs the same kernel on throw-away buffers and
 compares with the process group's all-reduce; any mismatch, mapping failure or timed-out wait makes the
-engine keep RCCL.  Waits are bounded by a wall-clock limit (``DTF_P2P_TIMEOUT_S``, default 60 s).
+engine keep RCCL.  Waits are bounded by a wall-clock limit (``DTF_P2P_TIMEOUT_S``, default 30 s; the kernels clip it
+to 40 s); once a wait has hit it, every later wait of the run gives up at once (the error word is checked first), so
+a dead link costs one limit, not one per step of a replayed graph.
 """
 from __future__ import annotations
 
@@ -77,7 +79,7 @@ def requested(backend: str) -> bool:
 
 
 def default_timeout_s() -> float:
-    return float(os.environ.get("DTF_P2P_TIMEOUT_S", "60"))
+    return float(os.environ.get("DTF_P2P_TIMEOUT_S", "30"))
 
 
 class _DevicePtr:

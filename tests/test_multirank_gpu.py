@@ -269,6 +269,44 @@ def test_bench_launch_line_with_two_ranks_sharing_the_gpu(config, expect):
     assert abs(d["value"] - 200 * 120 / (d["ms_per_step"] * 120 / 1e3)) < 1e-6 * d["value"]
 
 
+def _late_peer(rank, world, port, mode):
+    os.environ.update(DTF_P2P_ALLREDUCE="1", DTF_P2P_FUSED="1", DTF_P2P_MODE=mode, DTF_P2P_TIMEOUT_S="0.25")
+    import time
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=100, test_size=300, seed=rank)
+    st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, lr=0.5)
+    st.initialize(seed=3)
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=rank), 100, [100], fused_update=False)
+    eng = SyncReplicasEngine(prog, st, collective="all_reduce")
+    prog.prepare_graphs(32, 16)
+    torch.cuda.synchronize()
+    dist.barrier()
+    if rank == 1:
+        time.sleep(3.0)                     # this rank's first step comes long after the other's time limit
+    t0 = time.time()
+    prog.run(32, 16)                        # 2 graphs of 16 steps = 64 launches that wait for a peer
+    late = eng.p2p.timed_out()              # synchronises
+    waited = time.time() - t0
+    dist.barrier()
+    dist.destroy_process_group()
+    return {"late": bool(late), "waited": waited, "mode": eng.p2p_mode}
+
+
+@pytest.mark.parametrize("mode", ["replicated", "sharded"])
+def test_a_dead_link_costs_one_time_limit_not_one_per_step(mode):
+    """Rank 1 starts 3 s late, the limit of a peer wait is 0.25 s: rank 0's first wait runs into the limit, and the other
+    31 steps of its two graphs must give up at once (the kernels look at the error word first) instead of waiting
+    0.25 s each."""
+    res = run_ranks(_late_peer, 2, mode, timeout=120)
+    assert res[0]["mode"] == mode and res[0]["late"]
+    assert res[0]["waited"] < 2.0, res[0]
+
+
 def test_bench_wide_async_with_adam_on_the_device_side_engine():
     """`wide_mlp_async` (Adam) on the peer-mapped push/pull engine: the moments live next to the master slice in the
     owner's exported region, the bf16 products run on the pulled replica; two ranks sharing the GPU."""
