@@ -53,6 +53,9 @@ def parse_args(argv=None):
                     choices=["auto", "reduce_scatter", "all_reduce", "bucketed", "p2p_sharded", "p2p_replicated"])
     ap.add_argument("--staleness", type=int, default=None, help="async configs: pull every (staleness+1)-th step")
     ap.add_argument("--replicas_to_aggregate", type=int, default=None, help="sync configs: R (default: the number of workers)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "native"],
+                    help="one-worker reference MLP: hipGraph replay (auto, graph), or one native call that enqueues every "
+                         "kernel of the run (measured slower and noisier in a fresh process; kept for comparison)")
     ap.add_argument("--no_second_mode", action="store_true",
                     help="N>1, mlp_sync: skip the extra timed segment in the other update mode (async_value)")
     ap.add_argument("--cpu", action="store_true", help="run on CPU with gloo (functional check only)")

@@ -152,7 +152,16 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
         except RuntimeError as e:                           # a peer wait ran into its limit: raised on every rank
             sys.stderr.write(f"[bench] rank {rank}: transport trial failed ({e})\n")
             failed, selection = 1, None
-    if world == 1 and not force and device.type == "cuda" and prog.use_graphs and args.warmup > 0 and fast:
+    # --launch native: the run is enqueued by ONE native call instead of a graph replay.  In a loop the two are equal
+    # (20 steps: 244 vs 242 us, tools/short_run_probe.py), but in a fresh process, which is what a benchmark run is,
+    # the host's first pass through the launch loop is slow and noisy (13.4-18 us/step against 12.7 for the graph's
+    # first launch): graphs stay the default.
+    want = getattr(args, "launch", "auto")
+    native = (world == 1 and not force and device.type == "cuda" and fast and want == "native" and engine.native_launch_ok())
+    if want == "native" and not native:
+        raise SystemExit("--launch native: needs one GPU worker whose update is inside the step's own launches")
+    run = (lambda n: engine.run_native(n)) if native else (lambda n: engine.run(n, graph_steps))
+    if world == 1 and not force and device.type == "cuda" and prog.use_graphs and args.warmup > 0 and fast and not native:
         # one worker: nothing is decided during the warm-up, so the graphs of the warm-up AND of the timed run are
         # captured before either (capture takes milliseconds of host time during which the GPU would fall idle and
         # drop its clocks right in front of the timed region)
@@ -164,7 +173,7 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     # for a peer runs into its limit, EVERY rank rebuilds the job on RCCL and warms up again (one decision for all)
     try:
         if not failed and args.warmup > 0:
-            engine.run(args.warmup, graph_steps)
+            run(args.warmup)
     except RuntimeError as e:
         if engine.p2p is None or world == 1:
             raise
@@ -182,11 +191,13 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
             extra_steps = 0
             _sync_all(device, world)
             engine.run(args.warmup, graph_steps) if args.warmup > 0 else None
-    if not prepared:
+    if not prepared and not native:
         _prepare_graphs(prog, args, graph_steps, device, 1 if engine.fast else engine.rounds)
+    args._launch = "native schedule (one call enqueues every kernel of the run)" if native else (
+        "hipGraph replay" if prog.use_graphs else "eager")
     _sync_all(device, world)
     t0 = time.perf_counter()
-    engine.run(args.steps, graph_steps)
+    run(args.steps)
     _sync_all(device, world)
     dt = time.perf_counter() - t0
     dt = _max_over_ranks(dt, device, world)
@@ -242,7 +253,8 @@ def _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer
                    "peer_mapped_mode": engine.p2p_mode,
                    "peer_exchange_inside_backward_launch": bool(getattr(engine, "p2p_fused", False)) and getattr(engine, "p2p", None) is not None,
                    "post_update_accuracy_pass": not args.no_post_update_accuracy,
-                   "hip_graph": bool(prog.use_graphs), "params": state.layout.used},
+                   "hip_graph": bool(prog.use_graphs) and not str(getattr(args, "_launch", "")).startswith("native"),
+                   "launch": getattr(args, "_launch", None), "params": state.layout.used},
         "final_loss": last.loss,
     }
     if R != world:

@@ -426,15 +426,19 @@ class MLPProgram:
             self.start()
         if not self.native_launch_ok():
             raise RuntimeError("this program's steps need Python between them")
-        self.data.prepare(self.steps_enqueued, n_steps, self.B)
         saved = self.steps_enqueued
         scheds = []
         for q in range(self.P):                       # one schedule per buffer slot, built on first use
             self.steps_enqueued = q
             scheds.append(self._compute_schedule(q))
         self.steps_enqueued = saved
-        ops._lib.run_schedule_steps(scheds, saved % self.P, n_steps)
-        self.steps_enqueued = saved + n_steps
+        limit = self.data.max_steps_per_launch(self.B)         # a call may touch two epochs' permutations at most
+        while n_steps > 0:
+            n = min(n_steps, limit)
+            self.data.prepare(self.steps_enqueued, n, self.B)
+            ops._lib.run_schedule_steps(scheds, self.steps_enqueued % self.P, n)
+            self.steps_enqueued += n
+            n_steps -= n
 
     def run(self, n_steps: int, graph_steps: int = 64) -> None:
         """Enqueue ``n_steps`` steps; returns without waiting for the device."""

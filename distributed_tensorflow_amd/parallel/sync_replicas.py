@@ -367,6 +367,20 @@ class SyncReplicasEngine:
             st.apply_shard(self._rs_out, scale)
             self.coll.all_gather(st.params, st.param_shard)
 
+    def native_launch_ok(self) -> bool:
+        """One worker, update inside the step's own launches: a run can be enqueued by one native call."""
+        return bool(self.fast and self.world == 1 and not self.use_coll and self.p2p is None
+                    and self.program.native_launch_ok())
+
+    def run_native(self, n_steps: int) -> None:
+        """``run`` for a short run of one worker without hipGraphs: ONE native call enqueues every kernel of the
+        ``n_steps`` steps.  The first kernel starts ~5 us after the call where a graph's first launch needs ~16 us;
+        beyond a hundred steps the two are equal (``profiles/r2_mlp_step/short_run_probe_*``)."""
+        if not self.native_launch_ok():
+            raise RuntimeError("native launch: one worker with the update inside the step's launches only")
+        self.program.run_native(n_steps)
+        self.updates_applied += n_steps
+
     def run(self, n_steps: int, graph_steps: int = 64) -> None:
         """Run ``n_steps`` aggregated updates (each rank contributes as the R/num_workers ratio dictates)."""
         if self.fast:

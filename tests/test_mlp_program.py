@@ -269,6 +269,33 @@ def test_gpu_two_launch_step_matches_three_launch_step(monkeypatch, hidden, batc
     assert prog_2.post_correct_of_last_step() == prog_3.post_correct_of_last_step()
 
 
+@pytest.mark.gpu
+def test_gpu_native_multi_step_launch_equals_graph_replay():
+    """One native call that enqueues every kernel of a run (bench.py's path for short one-worker runs) against the
+    hipGraph replay of the same steps: same log, same parameters, bit for bit."""
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=200, test_size=300, seed=5)
+    out = []
+    for native in (True, False):
+        st = build_mlp_state(784, [100], 10, "cuda", lr=0.3)
+        st.initialize(seed=11)
+        prog = MLPProgram(st, DeviceDataset(ds.train, "cuda", shuffle_seed=5), 100, [100], fused_update=True)
+        eng = SyncReplicasEngine(prog, st)
+        assert eng.native_launch_ok()
+        if native:
+            eng.run_native(5)
+            eng.run_native(20)
+        else:
+            eng.run(5, 64)
+            eng.run(20, 64)
+        torch.cuda.synchronize()
+        assert eng.updates_applied == 25 and st.global_step() == 26
+        out.append((st.params.clone(), prog.read_log(0, 25)))
+    assert torch.equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert a == b
+
+
 def _first_batch_problems(prog, split, seed):
     """What is wrong with a started program's view of its first batch (empty list = nothing): the uploaded split, the row
     indices the step tail wrote, the rows and labels gathered for the two-launch step."""
