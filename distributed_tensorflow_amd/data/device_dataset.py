@@ -34,14 +34,12 @@ class DeviceDataset:
 
     def _upload(self, array) -> torch.Tensor:
         """Host array -> device tensor through a page-locked copy of our own, read by a KERNEL over the host link
-        (``ops.upload_from_pinned``), and an explicit wait.  On some machines of the pool a split uploaded by the
-        copy engine into a re-used allocation (pageable or page-locked source alike) and read by the very next kernels
-        showed a few stale rows (labels still zero, images of another row); data written by a kernel is ordered and
-        coherent with the kernels behind it by the ordinary stream rules."""
+        (``ops.upload_from_pinned``), an explicit wait and a read-back check (``ops.h2d_verified``)."""
         t = torch.from_numpy(array)
         if self.device.type != "cuda":
             return t.to(self.device)
-        return self._kernel_upload(torch.empty(t.shape, dtype=t.dtype, device=self.device), t.contiguous().pin_memory())
+        from .. import ops
+        return ops.h2d_verified(torch.empty(t.shape, dtype=t.dtype, device=self.device), t, "dataset split")
 
     def _kernel_upload(self, out: torch.Tensor, staged: torch.Tensor, wait: bool = True):
         """Returns ``out`` after waiting for the copy, or (``wait=False``) an event that marks its end: the stream is

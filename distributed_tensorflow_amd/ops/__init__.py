@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import sys
+
 import torch
 
 from . import _lib, reference
@@ -648,6 +650,42 @@ def upload_from_pinned(dst, src):
     _lib.check(_lib.kernels().dtf_upload_words(dst.data_ptr(), src.data_ptr(), dst.numel(), _lib.stream_handle()),
                "upload_from_pinned")
     return dst
+
+
+def h2d_verified(dst, src, what: str = "tensor", attempts: int = 3):
+    """``dst`` (tensor on the GPU, any view) = ``src`` (host tensor of the same shape; converted to ``dst``'s dtype),
+    checked by reading it back, and written again when the device does not hold what was sent.
+
+    Set-up paths only (dataset, restored or injected parameters): it waits for the device.  The data travels by
+    ``upload_from_pinned`` (a kernel reading page-locked host memory) when ``dst`` is contiguous 4-byte data and the
+    kernel library is there, otherwise by PyTorch's copy.  Why the read-back: on some machines of the pool the first
+    step of a freshly built program was occasionally seen computing on data that differed from what had just been
+    uploaded (label rows still zero, parameters of the previous initialisation) although every copy had completed in
+    stream order; the read-back makes the runtime write back whatever the caches still hold for that memory and shows
+    whether the upload survived."""
+    if not dst.is_cuda:
+        dst.copy_(src)
+        return dst
+    host = src.detach().to(dtype=dst.dtype, device="cpu").contiguous()
+    if tuple(host.shape) != tuple(dst.shape):
+        raise ValueError(f"h2d_verified: {what}: shape {tuple(host.shape)} != {tuple(dst.shape)}")
+    by_kernel = dst.is_contiguous() and dst.element_size() == 4 and dst.numel() > 0 and _lib.kernels_available()
+    staged = host.pin_memory() if by_kernel else host
+    as_bits = (lambda t: t.view(torch.int32)) if dst.element_size() == 4 and dst.is_contiguous() else (lambda t: t)
+    with torch.cuda.device(dst.device):
+        for attempt in range(attempts):
+            if by_kernel:
+                upload_from_pinned(dst, staged)
+            else:
+                dst.copy_(staged)
+            torch.cuda.current_stream().synchronize()
+            back = dst.detach().cpu()
+            if torch.equal(as_bits(back), as_bits(host)):
+                return dst
+            bad = int((as_bits(back) != as_bits(host)).sum())
+            sys.stderr.write(f"[h2d] {what}: {bad} of {host.numel()} elements on the device differ from what was uploaded "
+                             f"(attempt {attempt + 1} of {attempts}); uploading again\n")
+    raise RuntimeError(f"h2d_verified: {what}: the device does not hold the uploaded data after {attempts} attempts")
 
 
 def truncated_normal_(out, stddev, seed, stream_id=0):

@@ -130,15 +130,18 @@ class AsyncParameterServerEngine:
             return self._gs
 
     def _apply(self, master: torch.Tensor, grad: torch.Tensor) -> None:
-        """One lock-free optimizer application on the owned slice."""
+        """One optimizer application on the owned slice.  SGD is lock-free (Hogwild: the reference's optimizer without
+        ``use_locking``, /root/reference/distributed.py:89).  Adam is applied under a lock: its update reads and
+        writes three buffers (parameters, m, v), and two service threads interleaving inside it pair one gradient's
+        first moment with another's second moment, which was seen to throw a run onto the loss plateau about once in
+        ten runs of three workers."""
         st = self.state
         if st.optimizer == "sgd":
             ops.sgd_apply(master, grad, st.lr, 1.0)
             return
         with self._gs_lock:
             self._adam_t += 1
-            t = self._adam_t
-        ops.adam_apply(master, grad, self._m, self._v, st.lr, st.beta1, st.beta2, st.eps, 1.0, step=t)
+            ops.adam_apply(master, grad, self._m, self._v, st.lr, st.beta1, st.beta2, st.eps, 1.0, step=self._adam_t)
 
     def _serve(self, w: int) -> None:
         try:

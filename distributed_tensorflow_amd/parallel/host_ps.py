@@ -35,6 +35,7 @@ import numpy as np
 import torch
 
 from ..cluster.spec import Role, parse_host_port, round_robin_placement
+from .. import ops
 from ..ops import _lib
 
 (OP_REGISTER, OP_INIT, OP_PULL, OP_PUSH_ASYNC, OP_INC_STEP, OP_GET_STEP, OP_SET_STEP, OP_ACC_APPLY, OP_TAKE_APPLY,
@@ -361,8 +362,12 @@ def run_role(role: Role, device, datasets, FLAGS) -> int:
         print('Starting chief queue runner and running init_tokens_op')
         engine.start_queue_runner()
 
-    val = (torch.from_numpy(datasets.validation.images).to(device), torch.from_numpy(datasets.validation.labels).to(device))
-    test = (torch.from_numpy(datasets.test.images).to(device), torch.from_numpy(datasets.test.labels).to(device))
+    def up(a):
+        t = torch.from_numpy(a)
+        return ops.h2d_verified(torch.empty(t.shape, dtype=t.dtype, device=device), t, "evaluation split")
+
+    val = (up(datasets.validation.images), up(datasets.validation.labels))
+    test = (up(datasets.test.images), up(datasets.test.labels))
     loop = train.TrainingLoop(role.task_index, prog, engine, FLAGS.train_steps, FLAGS.validation_every, FLAGS.log_every,
                               1, val, test, sv if is_chief else None, True, role.num_workers)
     loop.stop_check = lambda: engine.stopped

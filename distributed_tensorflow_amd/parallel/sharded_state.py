@@ -182,7 +182,7 @@ class ShardedState:
             val = torch.as_tensor(val, dtype=torch.float32)
             if tuple(val.shape) != tuple(dst.shape):
                 raise ValueError(f"{name}: shape {tuple(val.shape)} != {tuple(dst.shape)}")
-            dst.copy_(val)
+            ops.h2d_verified(dst, val, name)
         if global_step is not None:
             self.state[0] = int(global_step)
         self.initialized = True
@@ -234,8 +234,8 @@ class ShardedState:
             return False
         full_m, full_v, t = got
         lo, hi = self.shard
-        self.m.copy_(full_m[lo:hi])
-        self.v.copy_(full_v[lo:hi])
+        ops.h2d_verified(self.m, full_m[lo:hi], "Adam m")
+        ops.h2d_verified(self.v, full_v[lo:hi], "Adam v")
         self.state[2] = t
         return True
 

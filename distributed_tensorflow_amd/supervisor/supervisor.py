@@ -28,6 +28,8 @@ from typing import Callable, Dict, Optional
 import torch
 import torch.distributed as dist
 
+from .. import ops
+
 from ..checkpoint.saver import Saver, latest_checkpoint
 
 
@@ -128,8 +130,8 @@ class Supervisor:
         t = torch.zeros(1, dtype=torch.int32, device=st.device)
         if self.is_chief:
             full_m, full_v, steps = st.moments_from_values({k: torch.from_numpy(v) for k, v in self.restored_values.items()})
-            full[0].copy_(full_m)
-            full[1].copy_(full_v)
+            ops.h2d_verified(full[0], full_m, "Adam m")
+            ops.h2d_verified(full[1], full_v, "Adam v")
             t[0] = steps
         coll.broadcast(full, 0)
         coll.broadcast(t, 0)

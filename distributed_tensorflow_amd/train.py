@@ -294,8 +294,12 @@ def main(unused_argv=None) -> int:
     if FLAGS.sync_replicas and is_chief:
         print('Starting chief queue runner and running init_tokens_op')                    # :129
 
-    val = (torch.from_numpy(datasets.validation.images).to(device), torch.from_numpy(datasets.validation.labels).to(device))
-    test = (torch.from_numpy(datasets.test.images).to(device), torch.from_numpy(datasets.test.labels).to(device))
+    def up(a):
+        t = torch.from_numpy(a)
+        return ops.h2d_verified(torch.empty(t.shape, dtype=t.dtype, device=device), t, "evaluation split")
+
+    val = (up(datasets.validation.images), up(datasets.validation.labels))
+    test = (up(datasets.test.images), up(datasets.test.labels))
     loop = TrainingLoop(FLAGS.task_index, prog, engine, FLAGS.train_steps, FLAGS.validation_every, FLAGS.log_every,
                         FLAGS.steps_per_launch, val, test, sv, is_async, num_workers)
     train_time = loop.run()                                                                # :133-158
