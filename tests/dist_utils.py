@@ -15,6 +15,22 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+def init_one_rank_group(backend: str, **kwargs) -> None:
+    """A one-rank process group inside the calling process, on a free local port; another port is tried when somebody
+    else bound the chosen one between picking and listening (EADDRINUSE)."""
+    import torch.distributed as dist
+    last = None
+    for _ in range(5):
+        try:
+            dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, **kwargs)
+            return
+        except Exception as e:                     # DistNetworkError: the port was taken in the meantime
+            if "EADDRINUSE" not in str(e) and "address already in use" not in str(e):
+                raise
+            last = e
+    raise last
+
+
 def _entry(rank, world, port, fn, args, q):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:

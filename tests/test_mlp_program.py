@@ -15,11 +15,10 @@ def one_rank_rccl_group():
     """A one-rank RCCL process group for the tests that exercise the collective code paths on a single GPU; torn
     down afterwards so that it neither leaks into later tests nor outlives the interpreter."""
     import torch.distributed as dist
-    from dist_utils import free_port
+    from dist_utils import init_one_rank_group
     created = not dist.is_initialized()
     if created:
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
-                                device_id=torch.device("cuda", 0))
+        init_one_rank_group("nccl", device_id=torch.device("cuda", 0))
     yield
     if created and dist.is_initialized():
         torch.cuda.synchronize()
