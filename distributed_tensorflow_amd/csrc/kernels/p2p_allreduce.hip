@@ -23,6 +23,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 
 #include "dtf_kernels.h"
 
@@ -116,6 +119,46 @@ __global__ __launch_bounds__(256) void p2p_allreduce_sgd_kernel(P2PKernelArgs a)
 
 }  // namespace
 
+// Exported (uncached, IPC-mapped) regions are never returned to the driver while the process lives: a released region
+// goes to a free list and the next request of at most its size takes it again, zeroed.  Reason: device memory that had
+// been such a region, was freed, and then came back through an ordinary allocation was seen holding zeros in single
+// 128-byte lines no matter how often they were rewritten (the same lines on every machine tried: a program built
+// right after a one-rank peer-mapped engine had been torn down found parameters and labels missing).  A process
+// builds one or two engines in its life; only test processes build dozens.
+namespace {
+struct PooledRegion { void* p; size_t bytes; };
+std::mutex g_pool_mu;
+std::vector<PooledRegion> g_pool;
+std::unordered_map<void*, size_t> g_ipc_sizes;      // regions handed out by dtf_ipc_alloc
+
+void* region_acquire(size_t bytes) {
+  void* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t best = g_pool.size();
+    for (size_t i = 0; i < g_pool.size(); ++i)
+      if (g_pool[i].bytes >= bytes && (best == g_pool.size() || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+    if (best != g_pool.size()) {
+      p = g_pool[best].p;
+      g_pool.erase(g_pool.begin() + (long)best);
+    }
+  }
+  if (!p && hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) return nullptr;
+  if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;                                   // (the region stays allocated; nothing else will use it)
+  }
+  return p;
+}
+
+void region_release(void* p, size_t bytes) {
+  if (!p) return;
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool.push_back({p, bytes});
+}
+}  // namespace
+
 // Creates the communicator state of this rank and writes the 64-byte IPC handle of its region to handle_out.
 DTF_EXPORT void* dtf_p2p_create(int rank, int world, int64_t n_floats, char* handle_out) {
   if (rank < 0 || world < 1 || world > kMaxPeers || rank >= world || n_floats <= 0 || (n_floats & 3) || !handle_out) return nullptr;
@@ -123,18 +166,18 @@ DTF_EXPORT void* dtf_p2p_create(int rank, int world, int64_t n_floats, char* han
   P2PComm* c = new P2PComm;
   c->rank = rank; c->world = world; c->n = n_floats;
   c->bytes = region_bytes(n_floats);
-  void* p = nullptr;
-  if (hipExtMallocWithFlags(&p, c->bytes, hipDeviceMallocUncached) != hipSuccess) { delete c; return nullptr; }
+  void* p = region_acquire(c->bytes);
+  if (!p) { delete c; return nullptr; }
   c->local = static_cast<char*>(p);
-  if (hipMemset(p, 0, c->bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&c->err), 4 * sizeof(int)) != hipSuccess ||
+  if (hipMalloc(reinterpret_cast<void**>(&c->err), 4 * sizeof(int)) != hipSuccess ||
       hipMemset(c->err, 0, 4 * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-    (void)hipFree(p);
+    region_release(p, c->bytes);
     delete c;
     return nullptr;
   }
   hipIpcMemHandle_t h;
   if (hipIpcGetMemHandle(&h, p) != hipSuccess) {
-    (void)hipFree(p);
+    region_release(p, c->bytes);
     (void)hipFree(c->err);
     delete c;
     return nullptr;
@@ -421,7 +464,7 @@ DTF_EXPORT void dtf_p2p_destroy(void* comm) {
   if (!c) return;
   for (int p = 0; p < c->world; ++p)
     if (c->opened[p]) (void)hipIpcCloseMemHandle(c->peer[p]);
-  (void)hipFree(c->local);
+  region_release(c->local, c->bytes);
   (void)hipFree(c->err);
   delete c;
 }
@@ -536,14 +579,18 @@ DTF_EXPORT int dtf_async_push_pull(const DtfAsyncPushPullArgs* a, hipStream_t s)
 // Uncached device memory that other processes of the node can map: allocation + 64-byte IPC handle.
 DTF_EXPORT void* dtf_ipc_alloc(int64_t bytes, char* handle_out64) {
   if (bytes <= 0 || !handle_out64) return nullptr;
-  void* p = nullptr;
-  if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached) != hipSuccess) return nullptr;
+  void* p = region_acquire((size_t)bytes);
+  if (!p) return nullptr;
   hipIpcMemHandle_t h;
-  if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&h, p) != hipSuccess) {
-    (void)hipFree(p);
+  if (hipIpcGetMemHandle(&h, p) != hipSuccess) {
+    region_release(p, (size_t)bytes);
     return nullptr;
   }
   memcpy(handle_out64, &h, sizeof(h));
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_ipc_sizes[p] = (size_t)bytes;
+  }
   return p;
 }
 DTF_EXPORT void* dtf_ipc_open(const char* handle64) {
@@ -555,4 +602,16 @@ DTF_EXPORT void* dtf_ipc_open(const char* handle64) {
   return p;
 }
 DTF_EXPORT int dtf_ipc_close(void* p) { return p && hipIpcCloseMemHandle(p) == hipSuccess ? DTF_OK : DTF_ERR_ARG; }
-DTF_EXPORT int dtf_ipc_free(void* p) { return p && hipFree(p) == hipSuccess ? DTF_OK : DTF_ERR_ARG; }
+DTF_EXPORT int dtf_ipc_free(void* p) {
+  if (!p) return DTF_ERR_ARG;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_ipc_sizes.find(p);
+    if (it == g_ipc_sizes.end()) return DTF_ERR_ARG;
+    bytes = it->second;
+    g_ipc_sizes.erase(it);
+  }
+  region_release(p, bytes);                         // kept for the next engine of this process, see region_acquire
+  return DTF_OK;
+}

@@ -14,6 +14,9 @@ import torch
 from .mnist import DataSet, epoch_permutation
 
 
+_QUARANTINE = []      # device allocations that failed the read-back check; never freed, never used
+
+
 class DeviceDataset:
     def __init__(self, split: DataSet, device, shuffle_seed: int = 0, shuffle: bool = True):
         self.device = torch.device(device)
@@ -39,7 +42,16 @@ class DeviceDataset:
         if self.device.type != "cuda":
             return t.to(self.device)
         from .. import ops
-        return ops.h2d_verified(torch.empty(t.shape, dtype=t.dtype, device=self.device), t, "dataset split")
+        # Memory that does not hold what was written to it (seen on single machines of the pool: the same few words
+        # of one allocation, wrong on every attempt) is kept allocated, so that nothing else is placed there, and the
+        # split goes to another allocation.
+        for _ in range(4):
+            out = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+            try:
+                return ops.h2d_verified(out, t, "dataset split", attempts=2)
+            except RuntimeError:
+                _QUARANTINE.append(out)
+        raise RuntimeError("dataset upload: four different allocations did not hold the uploaded data")
 
     def _kernel_upload(self, out: torch.Tensor, staged: torch.Tensor, wait: bool = True):
         """Returns ``out`` after waiting for the copy, or (``wait=False``) an event that marks its end: the stream is

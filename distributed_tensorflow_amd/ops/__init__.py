@@ -682,9 +682,23 @@ def h2d_verified(dst, src, what: str = "tensor", attempts: int = 3):
             back = dst.detach().cpu()
             if torch.equal(as_bits(back), as_bits(host)):
                 return dst
-            bad = int((as_bits(back) != as_bits(host)).sum())
-            sys.stderr.write(f"[h2d] {what}: {bad} of {host.numel()} elements on the device differ from what was uploaded "
-                             f"(attempt {attempt + 1} of {attempts}); uploading again\n")
+            diff = (as_bits(back) != as_bits(host)).reshape(-1)
+            where = diff.nonzero().flatten()
+            sample = []
+            if dst.element_size() == 4 and dst.is_contiguous():
+                hb, db = as_bits(host).reshape(-1), as_bits(back).reshape(-1)
+                sample = [f"[{int(i)}] sent {int(hb[i]) & 0xffffffff:08x} holds {int(db[i]) & 0xffffffff:08x}" for i in where[:6]]
+            idx = where.tolist()
+            runs, start, prev = [], idx[0], idx[0]
+            for i in idx[1:] + [None]:
+                if i is None or i != prev + 1:
+                    runs.append((start, prev))
+                    start = i
+                prev = i
+            sample.append("runs " + " ".join(f"{a}-{b}" for a, b in runs[:24]) + (" ..." if len(runs) > 24 else ""))
+            sys.stderr.write(f"[h2d] {what}: {int(diff.sum())} of {host.numel()} elements at device address "
+                             f"{dst.data_ptr():#x} differ from what was uploaded (attempt {attempt + 1} of {attempts}; "
+                             f"first at element {int(where[0])}, last at {int(where[-1])}; {'; '.join(sample)})\n")
     raise RuntimeError(f"h2d_verified: {what}: the device does not hold the uploaded data after {attempts} attempts")
 
 
