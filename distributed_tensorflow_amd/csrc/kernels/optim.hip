@@ -184,9 +184,9 @@ DTF_EXPORT int dtf_accumulate(float* dst, const float* src, int64_t n, float alp
 // --------------------------------------------------------------------------------------
 // Upload by kernel: dst (device) = src (page-locked HOST memory, mapped into the device's address space), 4-byte
 // words, read over the host link by the shader cores.  The written data passes through the same caches as any kernel
-// output, so the kernels that read it next are ordered and coherent with it by the ordinary stream rules; used for
-// the resident dataset and the epoch permutations, where a copy-engine upload into a re-used allocation was seen
-// to leave a few stale rows on some machines.
+// output, so the kernels that read it next are ordered and coherent with it by the ordinary stream rules, and an
+// epoch's permutation can be uploaded in the middle of a run without draining the stream (the copy is one more
+// kernel in stream order; the staging buffer is guarded by an event).
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void upload_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * 256;

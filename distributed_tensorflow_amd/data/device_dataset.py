@@ -42,9 +42,9 @@ class DeviceDataset:
         if self.device.type != "cuda":
             return t.to(self.device)
         from .. import ops
-        # Memory that does not hold what was written to it (seen on single machines of the pool: the same few words
-        # of one allocation, wrong on every attempt) is kept allocated, so that nothing else is placed there, and the
-        # split goes to another allocation.
+        # Memory that does not hold what was written to it (seen with recycled exported regions, see
+        # ops.h2d_verified) is kept allocated, so that nothing else is placed there, and the split goes to another
+        # allocation.
         for _ in range(4):
             out = torch.empty(t.shape, dtype=t.dtype, device=self.device)
             try:

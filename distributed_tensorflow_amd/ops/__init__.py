@@ -658,11 +658,10 @@ def h2d_verified(dst, src, what: str = "tensor", attempts: int = 3):
 
     Set-up paths only (dataset, restored or injected parameters): it waits for the device.  The data travels by
     ``upload_from_pinned`` (a kernel reading page-locked host memory) when ``dst`` is contiguous 4-byte data and the
-    kernel library is there, otherwise by PyTorch's copy.  Why the read-back: on some machines of the pool the first
-    step of a freshly built program was occasionally seen computing on data that differed from what had just been
-    uploaded (label rows still zero, parameters of the previous initialisation) although every copy had completed in
-    stream order; the read-back makes the runtime write back whatever the caches still hold for that memory and shows
-    whether the upload survived."""
+    kernel library is there, otherwise by PyTorch's copy.  Why the read-back: it is what showed that device memory
+    which had been an exported uncached region (``csrc/kernels/p2p_allreduce.hip``), was freed and then handed out
+    again by the allocator can hold 128-byte lines that stay zero whatever is written to them; those regions are
+    pooled now, and this check stays as the tripwire for anything of that kind."""
     if not dst.is_cuda:
         dst.copy_(src)
         return dst
