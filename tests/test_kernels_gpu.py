@@ -277,3 +277,52 @@ def test_upload_from_pinned_is_a_plain_copy():
         ops.upload_from_pinned(dst, torch.zeros(3000, 7))               # pageable
     with pytest.raises(ValueError):
         ops.upload_from_pinned(dst, torch.zeros(10).pin_memory())       # size
+
+
+def test_h2d_verified_copies_views_and_converts():
+    """The checked set-up upload: contiguous 4-byte data (kernel path), a strided view and a dtype conversion
+    (PyTorch's copy), each compared with the source after the call."""
+    src = torch.randn(37, 53)
+    dst = torch.zeros(37, 53, device=DEV)
+    assert ops.h2d_verified(dst, src, "t") is dst and torch.equal(dst.cpu(), src)
+    flat = torch.zeros(4096, device=DEV)
+    view = flat[128:128 + 37 * 53].view(37, 53)                   # a variable inside a flat parameter buffer
+    ops.h2d_verified(view, src, "view")
+    assert torch.equal(flat[128:128 + 37 * 53].cpu().view(37, 53), src) and float(flat[:128].abs().sum()) == 0.0
+    wide = torch.zeros(37, 64, device=DEV)
+    ops.h2d_verified(wide[:, :53], src, "strided")                # not contiguous
+    assert torch.equal(wide[:, :53].cpu(), src) and float(wide[:, 53:].abs().sum()) == 0.0
+    half = torch.zeros(37, 53, dtype=torch.bfloat16, device=DEV)
+    ops.h2d_verified(half, src, "bf16")
+    assert torch.equal(half.cpu(), src.to(torch.bfloat16))
+    with pytest.raises(ValueError):
+        ops.h2d_verified(dst, torch.zeros(3, 3), "shape")
+
+
+def test_exported_regions_are_pooled_not_freed():
+    """An exported (uncached, IPC-mapped) region that is released goes to a pool of the process and the next request
+    that fits takes it again, zeroed: such memory is never handed back to the driver."""
+    import ctypes as C
+    from distributed_tensorflow_amd.ops import _lib
+    from distributed_tensorflow_amd.parallel.async_peer import _DevicePtr
+    lib = _lib.kernels()
+    lib.dtf_ipc_alloc.restype = C.c_void_p
+    lib.dtf_ipc_alloc.argtypes = [C.c_int64, C.c_char_p]
+    lib.dtf_ipc_free.restype = C.c_int
+    lib.dtf_ipc_free.argtypes = [C.c_void_p]
+    torch.zeros(1, device=DEV)
+    h = C.create_string_buffer(64)
+    nbytes = 3 << 20
+    p = lib.dtf_ipc_alloc(nbytes, h)
+    assert p
+    t = torch.as_tensor(_DevicePtr(p, nbytes // 4, "<f4"), device=DEV)
+    t.fill_(7.0)
+    torch.cuda.synchronize()
+    del t
+    assert lib.dtf_ipc_free(p) == 0 and lib.dtf_ipc_free(p) != 0           # the second release is refused
+    q = lib.dtf_ipc_alloc(nbytes - 4096, h)                                   # fits: the pooled region comes back
+    assert q == p
+    t = torch.as_tensor(_DevicePtr(q, (nbytes - 4096) // 4, "<f4"), device=DEV)
+    assert float(t.abs().sum()) == 0.0                                        # zeroed for its new user
+    del t
+    assert lib.dtf_ipc_free(q) == 0
