@@ -67,3 +67,16 @@ def test_async_adam_moments_live_with_the_owner():
     for r in res:
         assert r["last"] < r["first"] - 0.03         # Hogwild + stale Adam moments: run-to-run variation is large
         assert r["acc"] > 0.2                        # (chance: 0.1)
+
+
+@pytest.mark.slow
+def test_async_eight_workers_eight_shards():
+    """The shape of an 8-GPU node on the send/recv engine (every rank owns a shard and serves the seven others through
+    doorbell + payload exchanges, Adam moments with the owners): no rank waits on another forever, every owner applies
+    one gradient slice per worker step, global_step counts every update."""
+    world, steps = 8, 12
+    res = run_ranks(_async_worker, world, world, 1, steps, "adam", timeout=300)
+    assert res[0]["final_gs"] == 1 + world * steps
+    for r in res:
+        assert r["applied"] == world * steps
+        assert r["last"] < r["first"] - 0.2
