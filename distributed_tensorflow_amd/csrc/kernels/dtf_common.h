@@ -45,3 +45,16 @@ __device__ __forceinline__ int dtf_xcd_remap(int orig, int nwg) {
   int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + orig / NX;
 }
+
+
+// One Adam element update, the single statement of it that every kernel uses (flat optimizer, ranges, the folded
+// weight-gradient epilogue, the async push): lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) and eps_t = eps * sqrt(1 - b2^t)
+// are computed once per launch.  Square root and reciprocal are the hardware instructions (v_sqrt_f32, v_rcp_f32, 1 ulp
+// each): the IEEE-exact division and square root cost ~25 instructions per element, which made the folded epilogue
+// (128 elements per lane) spend as long in the vector ALU as in memory; 2 ulp on a step of relative size lr is far
+// below the rounding of the parameter itself.
+__device__ __forceinline__ void dtf_adam_one(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps_t) {
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  p -= lr_t * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps_t);
+}

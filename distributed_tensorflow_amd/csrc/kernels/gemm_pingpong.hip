@@ -277,10 +277,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
             for (int e = 0; e < 4; ++e) {
               if (adam) {
                 float a = pq[u][e], b = mq[u][e], c = vq[u][e];
-                const float g1 = gq[u][e] * 1.0f;
-                b = p.opt_b1 * b + (1.f - p.opt_b1) * g1;
-                c = p.opt_b2 * c + (1.f - p.opt_b2) * g1 * g1;
-                a -= lr_t * b / (sqrtf(c) + eps_t);
+                dtf_adam_one(a, gq[u][e] * 1.0f, b, c, lr_t, p.opt_b1, p.opt_b2, eps_t);
                 pq[u][e] = a; mq[u][e] = b; vq[u][e] = c;
               } else {
                 pq[u][e] -= lr_t * gq[u][e];

@@ -42,9 +42,7 @@ DTF_EXPORT int dtf_sgd_apply(float* param, const float* grad, int64_t n, float l
 // Adam with bias correction; the step number is read from device memory so the
 // launch can sit inside a replayed hipGraph.
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps_t) {
-  m = b1 * m + (1.f - b1) * g;
-  v = b2 * v + (1.f - b2) * g * g;
-  p -= lr_t * m / (sqrtf(v) + eps_t);
+  dtf_adam_one(p, g, m, v, lr_t, b1, b2, eps_t);
 }
 
 __global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,

@@ -518,7 +518,8 @@ __global__ __launch_bounds__(256) void async_push_pull_kernel(DtfAsyncPushPullAr
         mm = a.b1 * mm + (1.f - a.b1) * g;
         vv = a.b2 * vv + (1.f - a.b2) * (g * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nv[j] = v[j] - lr_t * mm[j] / (sqrtf(vv[j]) + a.eps);
+        for (int j = 0; j < 4; ++j)      // hardware square root and reciprocal, as in dtf_adam_one
+          nv[j] = v[j] - lr_t * mm[j] * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv[j]) + a.eps);
         __builtin_nontemporal_store(mm, mp);
         __builtin_nontemporal_store(vv, vp);
       }
