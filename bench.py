@@ -25,6 +25,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -110,6 +111,14 @@ def launch_workers(args, argv) -> int:
         t = threading.Thread(target=_pump, args=(procs[r].stdout, sys.stderr, f"[rank {r} stdout] "), daemon=True)
         t.start()
         pumps.append(t)
+    def stop_children(signum, _frame):                            # the launcher is told to stop: so are its workers
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        sys.exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, stop_children)
     rc = 0
     pending = set(range(n))
     while pending:

@@ -59,3 +59,29 @@ def test_bench_starts_its_own_two_gpu_workers_sharing_the_gpu(config):
                               {"DTF_SHARE_GPU": "1", "DTF_DIST_BACKEND": "gloo", "DTF_P2P_ALLREDUCE": "1", "DTF_PEER_ASYNC": "1"}))
     assert d["n_gpus"] == 2 and d["steps"] == 60 and d["value"] > 0
     assert d["config"]["global_batch"] == 200
+
+
+def test_bench_launcher_stops_its_workers_when_it_is_told_to_stop():
+    """SIGTERM to the self-launching bench.py ends the worker processes it started (nothing is left behind for the
+    next job on the machine)."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--cpu", "--steps", "100000",
+                          "--warmup", "1", "--no_second_mode"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    deadline = time.time() + 120
+    kids = []
+    while time.time() < deadline and len(kids) < 2:             # wait until both workers exist
+        out = subprocess.run(["ps", "-o", "pid=", "--ppid", str(p.pid)], capture_output=True, text=True).stdout.split()
+        kids = [int(k) for k in out]
+        time.sleep(0.2)
+    assert len(kids) == 2, kids
+    time.sleep(1.0)
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    deadline = time.time() + 20
+    while time.time() < deadline and any(os.path.exists(f"/proc/{k}") for k in kids):
+        time.sleep(0.2)
+    assert not any(os.path.exists(f"/proc/{k}") for k in kids)
