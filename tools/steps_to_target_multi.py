@@ -33,6 +33,7 @@ ap.add_argument("--max_steps", type=int, default=20000, help="local steps per wo
 ap.add_argument("--lr", type=float, default=0.01)
 ap.add_argument("--batch", type=int, default=100)
 ap.add_argument("--chunk", type=int, default=16, help="local steps between checks")
+ap.add_argument("--staleness", type=int, default=4, help="async: pull every (staleness+1)-th step")
 a = ap.parse_args()
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -49,7 +50,7 @@ if a.mode == "sync":
     eng = SyncReplicasEngine(prog, st)
 else:
     prog = MLPProgram(st, data, a.batch, [100], fused_update=False, gs_inc=0, log_capacity=2048)
-    eng = make_async_engine(prog, st, 1, 4)
+    eng = make_async_engine(prog, st, 1, a.staleness)
 cpu = dist.get_backend() != "nccl"
 losses, hit_gs, local_steps = [], None, 0
 while local_steps < a.max_steps:
@@ -71,6 +72,8 @@ if rank == 0:
     print(json.dumps({"metric": "steps to target loss", "mode": a.mode, "workers": world, "target": a.target,
                       "global_step": hit_gs, "local_steps_per_worker": local_steps, "examples": local_steps * a.batch * world,
                       "lr": a.lr, "batch_per_worker": a.batch, "loss": "reference (softmax applied twice)",
-                      "final_loss_rank0": losses[-1], "engine": type(eng).__name__}), flush=True)
+                      "final_loss_rank0": losses[-1], "engine": type(eng).__name__,
+                      "transport": getattr(eng, "transport", None), "staleness": a.staleness if a.mode == "async" else None}),
+          flush=True)
 dist.barrier()
 dist.destroy_process_group()
