@@ -188,7 +188,14 @@ struct DtfMlp2Shard {
   long long n;              // floats per flat buffer
   int rank, world;
   unsigned timeout_ticks;   // of the 100 MHz constant clock
-  int pad_;
+  int adam;                 // 1: the owner applies Adam with the moments below (its ps-resident slot variables)
+  // Adam on the owner: flat moment buffers of this rank (only the entries of tiles it owns are ever touched), the
+  // true learning rate and the factor that turns the sum over the ranks into the aggregated gradient (1 / R);
+  // update number = number of this step + adam_t_offset
+  float* m;
+  float* v;
+  float adam_lr, grad_scale, b1, b2, eps;
+  int adam_t_offset;
 };
 
 // Asynchronous push/pull inside launch 2 (mode 3; see the async section of p2p_allreduce.hip): every weight-

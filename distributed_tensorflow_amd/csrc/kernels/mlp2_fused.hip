@@ -539,6 +539,17 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
       woff[r] = wok[r] ? (size_t)(Wt - sh.params_base) + (size_t)row * N + n0 + fr : 0;
     }
     const size_t boff = b_lane ? (size_t)(bt - sh.params_base) + n0 + fr : 0;
+    // Adam: the owner's moments of these tiles are requested before the wait for the peers
+    float am[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f}, abm = 0.f, abv = 0.f;
+    if (owner4 && sh.adam) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        am[r] = sh.m[woff[r]];
+        av[r] = sh.v[woff[r]];
+      }
+      abm = sh.m[boff];
+      abv = sh.v[boff];
+    }
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     if (!owner4) {
       // my contribution into the owner's inbox (row `me`), then the flag: stores and flag are system scope on
@@ -615,10 +626,34 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
         for (int r = 0; r < 4; ++r) sv[r] += k == me ? gv[r] : pv[k][r];
         sb += k == me ? bsum : pb[k];
       }
-    float nv[4];
+    float nv[4], nb;
+    if (sh.adam) {
+      // the owner keeps m and v of its tiles (the slot variables live where the variable lives, as on a ps task);
+      // same element update as the flat optimizer kernels
+      const float t = (float)(seq + sh.adam_t_offset);
+      const float bc1 = 1.f - powf(sh.b1, t), bc2 = 1.f - powf(sh.b2, t);
+      const float sq = sqrtf(bc2);
+      const float lr_t = sh.adam_lr * sq / bc1, eps_t = sh.eps * sq;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) nv[r] = wold[r] - p.lr * sv[r];
-    const float nb = bold - p.lr * sb;
+      for (int r = 0; r < 4; ++r) {
+        nv[r] = wold[r];
+        dtf_adam_one(nv[r], sv[r] * sh.grad_scale, am[r], av[r], lr_t, sh.b1, sh.b2, eps_t);
+        if (wok[r]) {
+          sh.m[woff[r]] = am[r];
+          sh.v[woff[r]] = av[r];
+        }
+      }
+      nb = bold;
+      dtf_adam_one(nb, sb * sh.grad_scale, abm, abv, lr_t, sh.b1, sh.b2, eps_t);
+      if (b_lane) {
+        sh.m[boff] = abm;
+        sh.v[boff] = abv;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nv[r] = wold[r] - p.lr * sv[r];
+      nb = bold - p.lr * sb;
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       if (k < world && k != me) {
@@ -767,6 +802,9 @@ static int mlp2_validate(const DtfMlp2Args* a) {
       return DTF_ERR_ARG;
     for (int k = 0; k < sh.world; ++k)
       if (!sh.region[k]) return DTF_ERR_ARG;
+    if (sh.adam && (!sh.m || !sh.v || !(sh.adam_lr > 0.f) || !(sh.grad_scale > 0.f) || !(sh.b1 >= 0.f && sh.b1 < 1.f) ||
+                    !(sh.b2 >= 0.f && sh.b2 < 1.f) || !(sh.eps > 0.f)))
+      return DTF_ERR_ARG;
     // the four parameter tensors must be views into the flat buffer whose offsets address the boxes
     const float* lo = sh.params_base;
     const float* hi = lo + sh.n;

@@ -128,7 +128,9 @@ class Mlp2Shard(C.Structure):
     """Mirror of ``DtfMlp2Shard``: regions of all ranks and the box / flag offsets of the sharded exchange."""
     _fields_ = [("region", C.c_void_p * 8), ("params_base", C.c_void_p), ("err", C.c_void_p), ("inbox_off", C.c_longlong),
                 ("outbox_off", C.c_longlong), ("inflag_off", C.c_longlong), ("outflag_off", C.c_longlong), ("n", C.c_longlong),
-                ("rank", C.c_int), ("world", C.c_int), ("timeout_ticks", C.c_uint), ("pad_", C.c_int)]
+                ("rank", C.c_int), ("world", C.c_int), ("timeout_ticks", C.c_uint), ("adam", C.c_int),
+                ("m", C.c_void_p), ("v", C.c_void_p), ("adam_lr", C.c_float), ("grad_scale", C.c_float), ("b1", C.c_float),
+                ("b2", C.c_float), ("eps", C.c_float), ("adam_t_offset", C.c_int)]
 
 
 class Mlp2Args(C.Structure):

@@ -135,14 +135,25 @@ class P2PAllReduce:
         _lib.check(_lib_k().dtf_p2p_mlp2_peer(self._comm, slot, self.timeout_s, C.byref(out)), "p2p_mlp2_peer")
         return out
 
-    def mlp2_shard(self, params: torch.Tensor) -> "_lib.Mlp2Shard":
+    def mlp2_shard(self, params: torch.Tensor, adam: Optional[dict] = None) -> "_lib.Mlp2Shard":
         """Regions and box offsets for the two-launch step's sharded exchange (``mlp2_fused.hip``, mode 4): workgroup w
-        belongs to rank ``w % world``, which sums the contributions, updates and redistributes the tiles."""
+        belongs to rank ``w % world``, which sums the contributions, updates and redistributes the tiles.  ``adam``:
+        ``{m, v (flat float32 buffers of this rank, laid out like params), lr, grad_scale, beta1, beta2, eps,
+        t_offset}`` makes the owner apply Adam with its own moments instead of SGD."""
         if params.numel() != self.n or params.dtype != torch.float32 or not params.is_contiguous():
             raise ValueError("p2p sharded exchange: params must be the flat float32 buffer the boxes were sized for")
         out = _lib.Mlp2Shard()
         _lib.check(_lib_k().dtf_p2p_mlp2_shard(self._comm, self.timeout_s, C.byref(out)), "p2p_mlp2_shard")
         out.params_base = params.data_ptr()
+        if adam is not None:
+            for name in ("m", "v"):
+                t = adam[name]
+                if t.numel() != self.n or t.dtype != torch.float32 or not t.is_contiguous() or t.device != params.device:
+                    raise ValueError(f"p2p sharded exchange: Adam {name} must be a flat float32 buffer like params")
+            out.adam, out.m, out.v = 1, adam["m"].data_ptr(), adam["v"].data_ptr()
+            out.adam_lr, out.grad_scale = float(adam["lr"]), float(adam["grad_scale"])
+            out.b1, out.b2, out.eps = float(adam["beta1"]), float(adam["beta2"]), float(adam["eps"])
+            out.adam_t_offset = int(adam["t_offset"])
         return out
 
     def general_args(self, slot: int, params: torch.Tensor, acc: torch.Tensor, state: torch.Tensor, seq: torch.Tensor,

@@ -76,6 +76,8 @@ class SyncReplicasEngine:
         if collective == "auto":
             small = state.nbytes() < ALLREDUCE_BELOW_BYTES and state.optimizer == "sgd"
             collective = "all_reduce" if small else "reduce_scatter"
+            if state.nbytes() < ALLREDUCE_BELOW_BYTES and state.optimizer == "adam":
+                self._want_p2p = "sharded"      # small model with Adam: owner-resident moments on the sharded exchange
             # large state and a program that reports when parts of its gradient are complete: aggregate bucket by
             # bucket behind the backward pass (DTF_BUCKETED=0 keeps the single reduce-scatter after it)
             if (state.nbytes() >= BUCKETED_ABOVE_BYTES and self.use_coll and hasattr(program, "grad_groups")
@@ -199,14 +201,23 @@ class SyncReplicasEngine:
         st, prog = self.state, self.program
         # "auto": real multi-rank RCCL groups only; "1": also one-rank groups and gloo rehearsals
         wanted = p2p.requested("") or (p2p.requested(self.coll.backend) and self.world > 1)
-        eligible = (self._want_p2p is not None and st.optimizer == "sgd" and self.world <= 8
+        eligible = (self._want_p2p is not None and st.optimizer in ("sgd", "adam") and self.world <= 8
                     and getattr(prog, "fused2", False) and not prog.fused and prog.P == p2p.SLOTS)
-        if not (wanted and eligible):
+        fused = os.environ.get("DTF_P2P_FUSED", "1") != "0" and not (os.environ.get("DTF_SHARE_GPU") == "1" and self.world > 3)
+        # Adam exists on the sharded exchange inside the backward launch only (the owner of a tile keeps its moments)
+        if not (wanted and eligible) or (st.optimizer == "adam" and not fused):
             return False
         if not self._open_p2p(group):
             return False
         self.p2p_fused = os.environ.get("DTF_P2P_FUSED", "1") != "0"
-        self.p2p_mode = self._want_p2p
+        self.p2p_mode = "sharded" if st.optimizer == "adam" else self._want_p2p
+        self._adam = None
+        if st.optimizer == "adam":
+            # ps-resident slot variables: flat moment buffers on every rank, of which a rank only ever touches the
+            # tiles it owns; `loaded` = what they held when last published (zeros, or a restored checkpoint)
+            z = lambda: torch.zeros(st.layout.total, dtype=torch.float32, device=st.device)
+            self._adam = {"m": z(), "v": z(), "loaded_m": z(), "loaded_v": z(),
+                          "t_offset": int(st.state[2].item()) - int(st.state[1].item())}
         # replicas are compared after the first run() (a warm-up, as a rule) and then every so many run() calls
         self._replica_check_every = max(1, int(os.environ.get("DTF_REPLICA_CHECK_EVERY", "256")))
         self._runs_since_check = 0
@@ -283,7 +294,11 @@ class SyncReplicasEngine:
         if self.p2p_fused and self.p2p_mode == "sharded":
             # the backward launch sends every tile to its owner rank, which updates it and stores it into every replica
             prog.schedule_tail_fn = None
-            self._shard_struct = self.p2p.mlp2_shard(st.params)
+            adam = None
+            if self._adam is not None:
+                adam = {"m": self._adam["m"], "v": self._adam["v"], "lr": st.lr, "grad_scale": 1.0 / self.R,
+                        "beta1": st.beta1, "beta2": st.beta2, "eps": st.eps, "t_offset": self._adam["t_offset"]}
+            self._shard_struct = self.p2p.mlp2_shard(st.params, adam=adam)
             prog.use_sharded_exchange(self._shard_struct, st.lr / self.R)
         elif self.p2p_fused:
             # the backward launch exchanges gradient tiles with the peers and applies the update: two launches per step
@@ -305,8 +320,39 @@ class SyncReplicasEngine:
             raise RuntimeError("no peer-mapped transport is installed")
         if mode not in ("replicated", "sharded"):
             raise ValueError("mode must be 'replicated' or 'sharded'")
+        if mode != "sharded" and getattr(self, "_adam", None) is not None:
+            raise ValueError("Adam runs on the sharded exchange only (the owner of a tile keeps its moments)")
         self.p2p_mode = mode
         self._wire_p2p()
+
+    # ---- Adam on the sharded exchange: moments between the owners' buffers and the checkpointable slices
+    def publish_state(self) -> None:
+        """After the state was initialised or restored (collective): the owners' moment buffers take the moments the
+        ranks' slices hold, and the update count the kernels derive from the step number is re-based."""
+        if getattr(self, "_adam", None) is None:
+            return
+        st, a = self.state, self._adam
+        full = st.gather_moments(self.coll)
+        for key, src in (("m", full[0]), ("v", full[1])):
+            a[key].copy_(src)
+            a["loaded_" + key].copy_(src)
+        a["t_offset"] = int(st.state[2].item()) - int(st.state[1].item())
+        self._wire_p2p()
+
+    def moments_to_state(self) -> None:
+        """Before a checkpoint (collective): every element's moments come home from the rank that owns its tile (the
+        others still hold what was published, so the sum of the changes is the owner's change) into the slices
+        ``ShardedState`` saves, and the update counter follows the step counter."""
+        if getattr(self, "_adam", None) is None:
+            return
+        st, a = self.state, self._adam
+        torch.cuda.synchronize(st.device)
+        lo, hi = st.shard
+        for key, dst in (("m", st.m), ("v", st.v)):
+            delta = a[key] - a["loaded_" + key]
+            self.coll.all_reduce_sum(delta)
+            dst.copy_((a["loaded_" + key] + delta)[lo:hi])
+        st.state[2] = int(st.state[1].item()) + a["t_offset"]
 
     @property
     def transport(self) -> str:

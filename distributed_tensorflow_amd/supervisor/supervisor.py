@@ -74,6 +74,8 @@ class Supervisor:
             return None
         if self.engine is not None and hasattr(self.engine, "gather_moments"):
             return self.engine.gather_moments()              # async: one-sided, chief only
+        if self.engine is not None and hasattr(self.engine, "moments_to_state"):
+            self.engine.moments_to_state()                   # sync, owner-resident moments: back into the slices (collective)
         if self.group_size > 1 and dist.is_initialized():
             from ..parallel.comm import Collectives
             return st.gather_moments(Collectives())

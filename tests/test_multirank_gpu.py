@@ -269,6 +269,66 @@ def test_bench_launch_line_with_two_ranks_sharing_the_gpu(config, expect):
     assert abs(d["value"] - 200 * 120 / (d["ms_per_step"] * 120 / 1e3)) < 1e-6 * d["value"]
 
 
+def _sync_adam_gpu(rank, world, port, p2p, steps, resume_at):
+    os.environ["DTF_P2P_ALLREDUCE"] = "1" if p2p else "0"
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.comm import Collectives
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    ds = mnist.synthetic_data_sets(train_size=2000, validation_size=100, test_size=300, seed=rank)
+
+    def build():
+        st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, optimizer="adam", lr=2e-3)
+        st.initialize(seed=3)
+        prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=rank), 100, [100], fused_update=False)
+        return st, prog, SyncReplicasEngine(prog, st)
+
+    st, prog, eng = build()
+    assert (eng.p2p is not None and eng.p2p_mode == "sharded" and eng.p2p_fused) == p2p, eng.transport
+    eng.run(resume_at, 8)
+    saved = None
+    if p2p:
+        # checkpoint + restore in the middle: moments home to the slices, a fresh job, moments out to the owners again
+        eng.moments_to_state()
+        torch.cuda.synchronize()
+        full = st.gather_moments(Collectives())
+        saved = {n: st.var(n).cpu().clone() for n in st.names()}
+        saved.update(st.named_tensors(full))
+        eng.p2p.close()
+        st, prog, eng = build()
+        st.load_values(saved)
+        st.load_moments(saved)
+        eng.publish_state()
+    eng.run(steps - resume_at, 8)
+    eng.moments_to_state() if p2p else None
+    torch.cuda.synchronize()
+    full = st.gather_moments(Collectives())
+    out = {"params": st.params.cpu().numpy().copy(), "m": full[0].cpu().numpy().copy(), "v": full[1].cpu().numpy().copy(),
+           "gs": st.global_step(), "t": int(st.state[2].item()), "transport": eng.transport}
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def test_sync_adam_on_the_sharded_exchange_matches_the_collective_path():
+    """`--sync_replicas --optimizer adam` with two workers: the tile owners keep Adam's moments inside the backward
+    launch (sharded peer exchange).  Same trajectory as reduce-scatter -> shard Adam -> all-gather through the process
+    group, identical replicas, the same moments at the end, and a checkpoint / restore in the middle changes nothing."""
+    steps = 24
+    a = run_ranks(_sync_adam_gpu, 2, True, steps, 10, timeout=150)
+    b = run_ranks(_sync_adam_gpu, 2, False, steps, 10, timeout=150)
+    assert "sharded" in a[0]["transport"] and "sharded" not in b[0]["transport"]
+    assert (a[0]["params"] == a[1]["params"]).all()                       # replicas identical, bit for bit
+    assert a[0]["gs"] == b[0]["gs"] == steps + 1 and a[0]["t"] == b[0]["t"] == steps
+    import numpy as np
+    np.testing.assert_allclose(a[0]["params"], b[0]["params"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(a[0]["m"], b[0]["m"], rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(a[0]["v"], b[0]["v"], rtol=2e-3, atol=1e-9)
+
+
 def _late_peer(rank, world, port, mode):
     os.environ.update(DTF_P2P_ALLREDUCE="1", DTF_P2P_FUSED="1", DTF_P2P_MODE=mode, DTF_P2P_TIMEOUT_S="0.25")
     import time
