@@ -329,6 +329,60 @@ def test_sync_adam_on_the_sharded_exchange_matches_the_collective_path():
     np.testing.assert_allclose(a[0]["v"], b[0]["v"], rtol=2e-3, atol=1e-9)
 
 
+def _supervised_adam_resume(rank, world, port, logdir):
+    os.environ["DTF_P2P_ALLREDUCE"] = "1"
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    from distributed_tensorflow_amd.supervisor.supervisor import Supervisor
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    store = dist.distributed_c10d._get_default_store()
+    dev = torch.device("cuda", 0)
+    ds = mnist.synthetic_data_sets(train_size=700, validation_size=50, test_size=50, seed=40 + rank)
+
+    def build(sub):
+        st = build_mlp_state(784, [64], 10, dev, world_size=world, rank=rank, optimizer="adam", lr=0.01)
+        sv = Supervisor(rank == 0, os.path.join(logdir, sub), lambda: st.initialize(9), st, recovery_wait_secs=0.05,
+                        save_model_secs=600, store=store, group_size=world)
+        sv.prepare_or_wait_for_session()
+        prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=40 + rank), 50, [64], fused_update=False,
+                          post_update_accuracy=False)
+        eng = SyncReplicasEngine(prog, st)
+        sv.engine = eng
+        eng.publish_state()                       # what train.py does after the session is there
+        return st, prog, eng, sv
+
+    st_a, prog_a, eng_a, _ = build("a")
+    assert eng_a.p2p is not None and eng_a.p2p_mode == "sharded", eng_a.transport
+    eng_a.run(40, 8)
+    st_b, prog_b, eng_b, sv_b = build("b")
+    eng_b.run(20, 8)
+    sv_b.save()                                   # every rank: the moments come home through a collective
+    dist.barrier()
+    st_c, prog_c, eng_c, sv_c = build("b")        # a new job on the same directory
+    gs_restored = st_c.global_step()
+    eng_c.run(20, 8)
+    torch.cuda.synchronize()
+    out = {"a": st_a.params.cpu().numpy().copy(), "c": st_c.params.cpu().numpy().copy(), "gs_restored": gs_restored,
+           "gs": st_c.global_step(), "loss_a": [r.loss for r in prog_a.read_log(20, 20)],
+           "loss_c": [r.loss for r in prog_c.read_log(20, 20)]}
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def test_supervised_resume_with_adam_on_the_sharded_exchange(tmp_path):
+    """Two GPU workers, sync mode, Adam with the moments on the tile owners: 20 steps, Supervisor.save (moments gathered
+    from the owners under TF's slot names), a new job restores and publishes them, 20 more steps = 40 uninterrupted
+    ones bit for bit."""
+    res = run_ranks(_supervised_adam_resume, 2, str(tmp_path), timeout=200)
+    for r in res:
+        assert r["gs_restored"] == 21 and r["gs"] == 41
+        assert (r["a"] == r["c"]).all() and r["loss_a"] == r["loss_c"]
+    assert (res[0]["c"] == res[1]["c"]).all()
+
+
 def _late_peer(rank, world, port, mode):
     os.environ.update(DTF_P2P_ALLREDUCE="1", DTF_P2P_FUSED="1", DTF_P2P_MODE=mode, DTF_P2P_TIMEOUT_S="0.25")
     import time
