@@ -248,6 +248,42 @@ DTF_EXPORT int dtf_p2p_mlp2_peer(void* comm, int slot, double timeout_s, DtfMlp2
 // Fills `out` (except params_base) for the sharded exchange over the same communicator.
 DTF_EXPORT int dtf_p2p_mlp2_shard(void* comm, double timeout_s, DtfMlp2Shard* out);
 
+// One-launch pipelined step of the one-hidden-layer network for one worker with SGD (mlp_pipe.hip): the dependent
+// path of a step works on Q = X' W1'(two steps old) and Gram matrices of the batches instead of the materialised
+// weights; see the file header.  Buffers with two generations are indexed by the step's parity.
+struct DtfPipeArgs {
+  const float* X;           // [n, In] dataset rows (ldx)
+  const float* labels;      // [n, C]
+  float* Xa;                // [8][128][ldxa] gathered batch rows, column In = 1 (rows >= B and columns > In stay zero)
+  float* labg;              // [8][16][128] gathered label rows, class-major, zero padded
+  int* ridx;                // [8][ridx_len] dataset row of each logical row ([0,B) batch, [B,2B) the batch before it); host use
+  float* Wm;                // [2][KAp][HP] W1 with b1 as row In, zero padded
+  float* W2m;               // [2][HP][16] W2 with b2 as row Hd, zero padded
+  float* Q;                 // [2][16384] X'(s) W1'(s-2) - lr G(s,s-2) dz1(s-2), MFMA result layout per 16x16 tile
+  float* Z1;                // [2][16384] z1 of a step before the ReLU (what the next step's accuracy-only rows start from), same layout
+  int* labi;                // [8][128] class of each gathered row (argmax of its label row)
+  float* GG;                // [2][3][16384] Gram matrices of column batch c: X'(c) X'(c)^T, X'(c+1) X'(c)^T, X'(c+2) X'(c)^T, A-operand layout
+  float* D1;                // [2][16384] dz1 of a step (rows >= B zero), B-operand layout
+  float* P2;                // [2][8][HP][16] per row block: h'^T dz2
+  int* ctr;                 // [2][2] {global_step, local_step} a step reads (the tail writes the other generation)
+  float* W1; float* b1; float* W2; float* b2;         // flat parameters: read by the prime launch, written by the flush launch
+  int* wlog;                // [log_cap][DTF_WLOG_INTS]
+  int In, Hd, C, B, R;      // R = B, or 2B with the accuracy-only rows
+  int HP, KAp, ldxa;        // HP = Hd + 1 rounded up to 16, KAp = In + 1 rounded up to 16, ldxa = KAp
+  int ldx, ridx_len;
+  int q;                    // slot of the step, 0..7 (prime: slot before the first step; flush: slot after the last)
+  int loss_mode, log_cap;
+  int roles;                // bit set of workgroup roles in this launch
+  int flush;                // 1: role W writes W1 / b1 of the flat buffer
+  int prime;                // 1: role Q also builds Z1 of the batch before the first step
+  float lr, inv_b;
+  DtfTailArgs tail;         // state, perm, n_train, gs_inc
+};
+DTF_EXPORT int dtf_pipe_step(const DtfPipeArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_pipe_prime(const DtfPipeArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_pipe_flush(const DtfPipeArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_pipe_launch_roles(const DtfPipeArgs* a, hipStream_t s);
+
 // C[M,N] = A[M,K] . B[N,K]^T with both operands k-contiguous (see gemm_tiled.hip).
 // dtype: 0 = fp32, 1 = bf16 (fp32 accumulate).  epilogue: 0 forward (+bias, ReLU, optional transposed copy Ct
 // and fp32 copy C32), 1 backward (mask > 0, optional Ct), 2 weight gradient (C is always fp32; bias_out = row

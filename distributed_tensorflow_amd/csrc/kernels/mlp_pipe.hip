@@ -1,0 +1,745 @@
+// One-launch training step of the reference network x -> relu(x W1 + b1) -> softmax(h W2 + b2)
+// (math: /root/reference/distributed.py:78-89 and its autodiff), exact fp32 MFMA throughout, for ONE worker
+// with plain SGD.
+//
+// The two-launch step (mlp2_fused.hip) is bound by two dependent device-wide phases per step: the forward
+// product needs every tile of the updated W1, and the weight gradient needs the whole hidden layer (through the
+// logits).  Each phase change costs a kernel boundary (~2 us) plus a cold first touch of what the other phase
+// wrote.  This file removes one of the two by never waiting for W1 to be MATERIALISED.  With X'(s) the batch of
+// step s extended by a column of ones (so that b1 is row `In` of W1' and one product covers both),
+//
+//     W1'(s) = W1'(s-2) - lr X'(s-2)^T dz1(s-2) - lr X'(s-1)^T dz1(s-1)
+//     z1(s)  = X'(s) W1'(s)
+//            = [ X'(s) W1'(s-2) - lr G(s,s-2) dz1(s-2) ]  -  lr G(s,s-1) dz1(s-1),      G(a,b) = X'(a) X'(b)^T,
+//
+// the bracket (called Q(s)) depends on nothing newer than step s-2 and is computed, spread over the chip, one
+// launch EARLIER; the Gram matrices G depend on the data only and are computed one launch earlier still.  What is
+// left on the dependent path of step s is small: per 16 batch rows one workgroup computes
+// z1 = Q - lr G dz1(s-1) (a [16 x B] x [B x H] product), the logits, the loss, dz2 and dz1(s) - all row-local - and
+// every other quantity of the step is produced by workgroups of the same launch that nobody in that launch waits
+// for.  One launch per step, one kernel boundary per step.  The weight matrix itself follows one launch behind
+// (it is only read by the Q products), the output layer (101 x 10) is brought up to date by every row workgroup
+// from per-row-block partial gradients of the previous launch, and a run of steps ends with a flush launch that
+// writes W1, b1, W2, b2 of the last step into the flat parameter buffer; it begins with a prime launch that builds
+// Q of its first step from that buffer.  The accuracy-only rows (previous batch with the updated parameters,
+// distributed.py:148-149) need no product of their own: X'(s-1) W1'(s) = z1(s-1) - lr G(s-1,s-1) dz1(s-1), and
+// z1(s-1) is what the row workgroups of the previous launch computed (they keep it in Z1).
+//
+// Launch of step s, slot q = s mod 8, generation a = s & 1 (p = 1 - a):
+//   role L  row workgroups (train row blocks, then accuracy-only row blocks): the dependent path above; reads
+//           Q[a] (accuracy-only rows: Z1[p]), GG[p], D1[p], W2m[p], P2[p]; writes D1[a] (= dz1(s)), Z1[a] (= z1(s)),
+//           P2[a][row block], W2m[a], the log record
+//   role Q  Q[p] (for step s+1) = X'(s+1) Wm[p] - lr G(s+1,s-1) D1[p]
+//           (prime launch only: also Z1 of the batch before the first step from the flat parameters)
+//   role G  GG[a] = { G(s,s), G(s+1,s), G(s+2,s) }, one 16x16 tile per workgroup
+//   role W  Wm[a] = Wm[p] - lr X'(s-1)^T D1[p]            (flush: into W1 / b1 of the flat buffer)
+//   role T  counters, log header; gather of the batch of step s+3 (rows, label rows, label indices) through the
+//           row indices the previous launch selected, and selection of the row indices of step s+4 (no load of
+//           this role depends on more than one other load)
+//   role F  (flush only) W2, b2 of the flat buffer = W2m[p] - lr sum of P2[p]
+// Everything a launch reads of generation p was written by earlier launches; everything it writes is generation a
+// (or a slot no role of this launch reads), so the roles of one launch never depend on each other.
+#include "dtf_device.h"
+
+// Diagnostic build only (-DDTF_STAMPS): per-workgroup timestamps of the 100 MHz constant clock.
+#ifdef DTF_STAMPS
+__device__ unsigned long long* pipe_stamp_buf = nullptr;
+#define PIPE_STAMP(slot)                                                                                                       \
+  do {                                                                                                                         \
+    if (threadIdx.x == 0 && pipe_stamp_buf) pipe_stamp_buf[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+extern "C" __attribute__((visibility("default"))) int dtf_set_stamp_buffer_pipe(unsigned long long* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(pipe_stamp_buf), &p, sizeof(p));
+}
+// shader-clock counter into the same buffer (clock frequency under this load = cycles / elapsed constant-clock time)
+#define PIPE_STAMP_CYCLES(slot)                                                                                      \
+  do {                                                                                                               \
+    if (threadIdx.x == 0 && pipe_stamp_buf) pipe_stamp_buf[(size_t)blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define PIPE_STAMP(slot) do { } while (0)
+#define PIPE_STAMP_CYCLES(slot) do { } while (0)
+#endif
+
+// raw buffer load with a wave-uniform (scalar) offset added to the per-lane one; the range check covers the per-lane
+// offset only, so kOOB there returns 0 whatever the scalar part is
+__device__ __forceinline__ float pipe_bld_s(rsrc_t r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+#define PIPE_SLOTS 8
+#define PIPE_ROWS 128
+#define PIPE_LABG_SLOT (16 * PIPE_ROWS)
+#define PIPE_ROLE_L 1
+#define PIPE_ROLE_Q 2
+#define PIPE_ROLE_G 4
+#define PIPE_ROLE_W 8
+#define PIPE_ROLE_T 16
+#define PIPE_ROLE_F 32
+
+// Operand-layout storage: D1, the Gram matrices, Q and Z1 are only ever read as MFMA operands, so they are stored the
+// way a wave reads them - per 16x16 tile (8 x 8 tiles per matrix) 64 lanes x 4 consecutive values - and a fragment
+// load is one 16-byte load per lane, 1 KB contiguous per wave (row-major storage made every such load touch 4-16
+// separate cache lines, which cost the row workgroups 1.3 us per launch).
+//   B operand (D1: k = batch row, n = hidden column):   tile (n / 16, k / 16), lane = ((k % 16) / 4) * 16 + n % 16, e = k % 4
+//   A operand (Gram: i = row, k = column):              tile (i / 16, k / 16), lane = ((k % 16) / 4) * 16 + i % 16, e = k % 4
+//   C layout  (Q, Z1: MFMA result, row i, column n):    tile (i / 16, n / 16), lane = ((i % 16) / 4) * 16 + n % 16, e = i % 4
+#define PIPE_MAT 16384                    // floats per operand-layout matrix (8 x 8 tiles x 256)
+__host__ __device__ __forceinline__ unsigned pipe_frag(int t0, int t1, int lane) { return (unsigned)(((t0 * 8 + t1) * 64 + lane) * 4); }
+
+struct PipeDims {
+  int NT, KT, nL, nQ, nG, nW, nT, nF;
+};
+__host__ __device__ __forceinline__ PipeDims pipe_dims(const DtfPipeArgs& p, int nrb) {
+  PipeDims d;
+  const int post = p.R > p.B ? 1 : 0;
+  d.NT = p.HP >> 4;
+  d.KT = p.KAp >> 4;
+  d.nL = (p.roles & PIPE_ROLE_L) ? nrb * (1 + post) : 0;
+  d.nQ = (p.roles & PIPE_ROLE_Q) ? nrb * (1 + (p.prime ? post : 0)) * d.NT : 0;
+  d.nG = (p.roles & PIPE_ROLE_G) ? (2 + post) * nrb * nrb : 0;
+  d.nW = (p.roles & PIPE_ROLE_W) ? (d.KT * d.NT + 15) >> 4 : 0;
+  d.nT = (p.roles & PIPE_ROLE_T) ? (p.B + 31) >> 5 : 0;
+  d.nF = (p.roles & PIPE_ROLE_F) ? 1 : 0;
+  return d;
+}
+
+// sum of the 16 waves' partial accumulators: thread t < 256 owns one element of the 16x16 tile
+__device__ __forceinline__ float pipe_reduce16(float (*red)[4][64], int e_r, int e_ln) {
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) s += red[w][e_r][e_ln];
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// role Q: one 16x16 tile of Q(s+1) per 16-wave workgroup, split-K over the waves
+// ---------------------------------------------------------------------------------------------------------
+template <int NRB>
+__device__ __forceinline__ void pipe_role_q(const DtfPipeArgs& p, int idx, float* smem) {
+  float (*red)[4][64] = reinterpret_cast<float (*)[4][64]>(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, g = lane >> 4;
+  const int NT = p.HP >> 4;
+  const int rbq = idx / NT, nt = idx - rbq * NT;
+  const bool post = rbq >= NRB;                        // prime launch only: z1 of the batch before the first step
+  const int rb = post ? rbq - NRB : rbq;
+  const int m0 = rb * 16, n0 = nt * 16;
+  const int a = p.q & 1, pg = a ^ 1;
+  const int slot = post ? p.q : ((p.q + 1) & (PIPE_SLOTS - 1));
+  const unsigned slot_bytes = (unsigned)PIPE_ROWS * (unsigned)p.ldxa * 4u;
+  const rsrc_t rx = make_rsrc(p.Xa + (size_t)slot * PIPE_ROWS * p.ldxa, slot_bytes);
+  const rsrc_t rw = make_rsrc(p.Wm + (size_t)pg * p.KAp * p.HP, (unsigned)p.KAp * (unsigned)p.HP * 4u);
+  const rsrc_t rg = make_rsrc(p.GG + ((size_t)pg * 3 + 2) * PIPE_MAT, PIPE_MAT * 4u);
+  const rsrc_t rd = make_rsrc(p.D1 + (size_t)pg * PIPE_MAT, PIPE_MAT * 4u);
+  const int nX = p.KAp >> 4;
+  const unsigned hp4 = (unsigned)p.HP * 4u;
+  const unsigned bcol = (unsigned)(n0 + fr) * 4u;
+  float av[4][4], bv[4][4];
+  float scale[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = wave + 16 * i;                       // wave-uniform
+    scale[i] = 1.f;
+    if (c < nX) {
+      const unsigned k = (unsigned)(16 * c + 4 * g);
+      bld4(rx, (unsigned)(m0 + fr) * (unsigned)p.ldxa * 4u + k * 4u, av[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[i][j] = bld(rw, (k + j) * hp4 + bcol);
+    } else if (c - nX < NRB && !post) {
+      scale[i] = -p.lr;
+      bld4(rg, pipe_frag(rb, c - nX, lane) * 4u, av[i]);
+      bld4(rd, pipe_frag(nt, c - nX, lane) * 4u, bv[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[i][j] = bv[i][j] = 0.f;
+    }
+  }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc0 = MFMA16(av[i][0] * scale[i], bv[i][0], acc0);
+    acc1 = MFMA16(av[i][1] * scale[i], bv[i][1], acc1);
+    acc0 = MFMA16(av[i][2] * scale[i], bv[i][2], acc0);
+    acc1 = MFMA16(av[i][3] * scale[i], bv[i][3], acc1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
+  PIPE_STAMP(1);
+  __syncthreads();
+  PIPE_STAMP(2);
+  if (threadIdx.x < 256) {
+    const int e_r = (threadIdx.x >> 6) & 3, e_ln = threadIdx.x & 63;
+    const int e_rl = 4 * (e_ln >> 4) + e_r, e_cl = e_ln & 15;
+    const float s = pipe_reduce16(red, e_r, e_ln);
+    float* out = post ? p.Z1 + (size_t)a * PIPE_MAT : p.Q + (size_t)pg * PIPE_MAT;
+    out[pipe_frag(rb, nt, (e_rl >> 2) * 16 + e_cl) + (e_rl & 3)] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// role G: one 16x16 tile of a Gram matrix X'(s+kind) X'(s)^T per 16-wave workgroup
+// ---------------------------------------------------------------------------------------------------------
+template <int NRB>
+__device__ __forceinline__ void pipe_role_g(const DtfPipeArgs& p, int idx, float* smem) {
+  float (*red)[4][64] = reinterpret_cast<float (*)[4][64]>(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, g = lane >> 4;
+  int kind = idx / (NRB * NRB);
+  const int rem = idx - kind * NRB * NRB;
+  if (p.R <= p.B) kind += 1;                           // without accuracy-only rows G(s,s) is not needed
+  const int rbi = rem / NRB, cbj = rem - rbi * NRB;
+  const int m0 = rbi * 16, n0 = cbj * 16;
+  const int a = p.q & 1;
+  const unsigned slot_bytes = (unsigned)PIPE_ROWS * (unsigned)p.ldxa * 4u;
+  const rsrc_t ra = make_rsrc(p.Xa + (size_t)((p.q + kind) & (PIPE_SLOTS - 1)) * PIPE_ROWS * p.ldxa, slot_bytes);
+  const rsrc_t rb = make_rsrc(p.Xa + (size_t)p.q * PIPE_ROWS * p.ldxa, slot_bytes);
+  const int nX = p.KAp >> 4;
+  float av[4][4], bv[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = wave + 16 * i;
+    const unsigned k4 = (unsigned)(16 * c + 4 * g) * 4u;
+    bld4(ra, c < nX ? (unsigned)(m0 + fr) * (unsigned)p.ldxa * 4u + k4 : kOOB, av[i]);
+    bld4(rb, c < nX ? (unsigned)(n0 + fr) * (unsigned)p.ldxa * 4u + k4 : kOOB, bv[i]);
+  }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc0 = MFMA16(av[i][0], bv[i][0], acc0);
+    acc1 = MFMA16(av[i][1], bv[i][1], acc1);
+    acc0 = MFMA16(av[i][2], bv[i][2], acc0);
+    acc1 = MFMA16(av[i][3], bv[i][3], acc1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int e_r = (threadIdx.x >> 6) & 3, e_ln = threadIdx.x & 63;
+    const int e_rl = 4 * (e_ln >> 4) + e_r, e_cl = e_ln & 15;
+    const float s = pipe_reduce16(red, e_r, e_ln);
+    p.GG[((size_t)a * 3 + kind) * PIPE_MAT + pipe_frag(rbi, cbj, (e_cl >> 2) * 16 + e_rl) + (e_cl & 3)] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// role W: Wm[a] = Wm[p] - lr X'(s-1)^T D1[p], one 16x16 tile per wave (16 tiles per workgroup)
+// ---------------------------------------------------------------------------------------------------------
+template <int NRB>
+__device__ __forceinline__ void pipe_role_w(const DtfPipeArgs& p, int idx) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, g = lane >> 4;
+  const int NT = p.HP >> 4, KT = p.KAp >> 4;
+  const int tile = idx * 16 + wave;
+  if (tile >= KT * NT) return;
+  const int mt = tile / NT, nt = tile - mt * NT;
+  const int m0 = mt * 16, n0 = nt * 16;
+  const int a = p.q & 1, pg = a ^ 1;
+  const int slot = (p.q + PIPE_SLOTS - 1) & (PIPE_SLOTS - 1);
+  const unsigned slot_bytes = (unsigned)PIPE_ROWS * (unsigned)p.ldxa * 4u;
+  const rsrc_t rx = make_rsrc(p.Xa + (size_t)slot * PIPE_ROWS * p.ldxa, slot_bytes);
+  const rsrc_t rd = make_rsrc(p.D1 + (size_t)pg * PIPE_MAT, PIPE_MAT * 4u);
+  const rsrc_t rw = make_rsrc(p.Wm + (size_t)pg * p.KAp * p.HP, (unsigned)p.KAp * (unsigned)p.HP * 4u);
+  const unsigned ldx4 = (unsigned)p.ldxa * 4u, hp4 = (unsigned)p.HP * 4u;
+  const unsigned a_base = (unsigned)(4 * g) * ldx4 + (unsigned)(m0 + fr) * 4u;
+  float av[NRB][4], bv[NRB][4], wold[4];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) {
+    bld4(rd, pipe_frag(nt, rb, lane) * 4u, bv[rb]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) av[rb][j] = pipe_bld_s(rx, a_base, (unsigned)(16 * rb + j) * ldx4);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wold[r] = bld(rw, (unsigned)(m0 + 4 * g + r) * hp4 + (unsigned)(n0 + fr) * 4u);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) {
+    acc0 = MFMA16(av[rb][0], bv[rb][0], acc0);
+    acc1 = MFMA16(av[rb][1], bv[rb][1], acc1);
+    acc0 = MFMA16(av[rb][2], bv[rb][2], acc0);
+    acc1 = MFMA16(av[rb][3], bv[rb][3], acc1);
+  }
+  const int col = n0 + fr;
+  PIPE_STAMP(1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + 4 * g + r;
+    const float w = wold[r] - p.lr * (acc0[r] + acc1[r]);
+    if (p.flush) {
+      if (col < p.Hd) {
+        if (row < p.In) p.W1[(size_t)row * p.Hd + col] = w;
+        else if (row == p.In) p.b1[col] = w;
+      }
+    } else {
+      p.Wm[((size_t)a * p.KAp + row) * p.HP + col] = w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// role T: counters, log header, gather of the batch of step s+3, row indices of step s+4
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pipe_role_t(const DtfPipeArgs& p, int tb) {
+  const DtfTailArgs& t = p.tail;
+  const int tid = threadIdx.x;
+  const int a = p.q & 1;
+  const int B = p.B, C = p.C;
+  const int sub = tid >> 5, l = tid & 31;
+  const int i = 32 * tb + sub;
+  const int q3 = (p.q + 3) & (PIPE_SLOTS - 1), q4 = (p.q + 4) & (PIPE_SLOTS - 1);
+  PIPE_STAMP_CYCLES(2);
+  // both chains start here: (row index of step s+3 -> its data) and (counters -> permutation entry of step s+4)
+  const int row = i < B ? p.ridx[(size_t)q3 * p.ridx_len + i] : 0;
+  const int gs = p.ctr[2 * a], ls = p.ctr[2 * a + 1];
+  if (tb == 0 && tid == 0) {
+    int* rec = p.wlog + (size_t)DTF_WLOG_INTS * (ls % p.log_cap);
+    rec[0] = gs;       // value of global_step before this step's increment
+    rec[1] = ls;
+    p.ctr[2 * (a ^ 1)] = gs + t.gs_inc;
+    p.ctr[2 * (a ^ 1) + 1] = ls + 1;
+    t.state[0] = gs + t.gs_inc;
+    t.state[1] = ls + 1;
+  }
+  if (i >= B) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(p.X + (size_t)row * p.ldx);
+  float* drow = p.Xa + ((size_t)q3 * PIPE_ROWS + i) * p.ldxa;
+  f32x4* dst = reinterpret_cast<f32x4*>(drow);
+  const int n4 = p.In >> 2;
+  for (int base = 0; base < n4; base += 32 * 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = base + 32 * u + l;
+      v[u] = src[k < n4 ? k : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = base + 32 * u + l;
+      if (k < n4) dst[k] = v[u];
+    }
+  }
+  if (l == 17) drow[p.In] = 1.f;                       // the column that carries the bias row of W1'
+  if (l < 16) {
+    const float v = l < C ? p.labels[(size_t)row * C + l] : -__builtin_huge_valf();
+    p.labg[q3 * PIPE_LABG_SLOT + l * PIPE_ROWS + i] = l < C ? v : 0.f;
+    // class of the row for the accuracy count: argmax with lowest-index tie break (tf.argmax, distributed.py:83)
+    const float vmax = row16_max(v);
+    const int am = row16_min(v == vmax ? l : 16);
+    if (l == 0) p.labi[q3 * PIPE_ROWS + i] = am;
+  }
+  if (l == 16) {
+    const long long pos64 = (long long)(ls + 4) * B + i;
+    const long long epoch = pos64 / t.n_train;
+    const int pos = (int)(pos64 - epoch * t.n_train);
+    int* rn = p.ridx + (size_t)q4 * p.ridx_len;
+    rn[i] = t.perm ? t.perm[(size_t)(epoch & 1) * t.n_train + pos] : pos;
+    rn[B + i] = row;                                   // the batch before it: its accuracy-only rows
+  }
+  PIPE_STAMP(1);
+  PIPE_STAMP_CYCLES(3);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// output layer brought up to date: element e of W2'(s) = W2m[p][e] - lr * sum over row blocks of P2[p][rb][e]
+// ---------------------------------------------------------------------------------------------------------
+template <int NRB>
+struct PipeW2Loads {
+  float w, part[NRB];
+};
+template <int NRB>
+__device__ __forceinline__ void pipe_w2_request(PipeW2Loads<NRB>& o, rsrc_t rw2, rsrc_t rp2, unsigned e4, unsigned blk4) {
+  o.w = bld(rw2, e4);
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) o.part[rb] = pipe_bld_s(rp2, e4, (unsigned)rb * blk4);
+#ifdef PIPE_EXP_NO_P2
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) o.part[rb] = 0.f;
+#endif
+}
+template <int NRB>
+__device__ __forceinline__ float pipe_w2_value(const PipeW2Loads<NRB>& o, float lr) {
+  float s = 0.f;
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) s += o.part[rb];
+  return o.w - lr * s;
+}
+
+template <int NRB>
+__device__ __forceinline__ void pipe_role_f(const DtfPipeArgs& p) {
+  const int pg = (p.q & 1) ^ 1;
+  const unsigned blk4 = (unsigned)p.HP * 64u;
+  const rsrc_t rw2 = make_rsrc(p.W2m + (size_t)pg * p.HP * 16, blk4);
+  const rsrc_t rp2 = make_rsrc(p.P2 + (size_t)pg * 8 * p.HP * 16, 8u * blk4);
+  for (int e = threadIdx.x; e < p.HP * 16; e += 1024) {
+    PipeW2Loads<NRB> ld;
+    pipe_w2_request<NRB>(ld, rw2, rp2, (unsigned)e * 4u, blk4);
+    const float w = pipe_w2_value<NRB>(ld, p.lr);
+    const int k = e >> 4, c = e & 15;
+    if (c < p.C) {
+      if (k < p.Hd) p.W2[(size_t)k * p.C + c] = w;
+      else if (k == p.Hd) p.b2[c] = w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// role L: the dependent path of 16 batch rows
+// ---------------------------------------------------------------------------------------------------------
+// softmax / loss / gradient of one row spread over 16 lanes (lane & 15 = class), the formulas of the two-launch
+// step (distributed.py:81-87 and the autodiff of :102); the second softmax works on probabilities (values in
+// [0, 1]) and needs no maximum; `lab_class` = argmax of the label row, found when the row was gathered
+__device__ __forceinline__ void pipe_row_head(float zsum, float lab, int lab_class, bool cls_ok, bool grad_row, int fr,
+                                              int loss_mode, float inv_b, float& loss, int& hit, float& dz) {
+  const float NEG_INF = -__builtin_huge_valf();
+  const float z = cls_ok ? zsum : NEG_INF;
+  const float zmax = row16_max(z);
+  const float e1 = __expf(z - zmax);                 // 0 on the padding lanes
+  const float s1 = row16_sum(e1);
+  const float inv1 = __builtin_amdgcn_rcpf(s1);
+  float logp, gz;
+  if (loss_mode == 0) {
+    // softmax applied a second time on the probabilities (the reference feeds y as "logits")
+    const float y = e1 * inv1;
+    const float e2 = cls_ok ? __expf(y) : 0.f;
+    const float s2 = row16_sum(e2);
+    const float inv2 = __builtin_amdgcn_rcpf(s2);
+    logp = y - __logf(s2);
+    const float dy = cls_ok ? (e2 * inv2 - lab) * inv_b : 0.f;
+    const float dot = row16_sum(dy * y);
+    gz = (dy - dot) * y;
+  } else {
+    logp = (z - zmax) - __logf(s1);
+    gz = (e1 * inv1 - lab) * inv_b;
+  }
+  loss = -row16_sum(cls_ok ? lab * logp : 0.f);
+  const int am_y = row16_min((cls_ok && z == zmax) ? fr : 16);
+  hit = am_y == lab_class ? 1 : 0;
+  dz = (grad_row && cls_ok) ? gz : 0.f;
+}
+
+template <int NRB>
+__device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float* smem) {
+  // LDS carve-up (floats)
+  float (*part)[4][64] = reinterpret_cast<float (*)[4][64]>(smem);                    // [8][4][64]   stage-1 partials of the second K half
+  float (*w2s)[17] = reinterpret_cast<float (*)[17]>(smem + 2048);                    // [128][17]    W2'(s)
+  float (*hs)[16][17] = reinterpret_cast<float (*)[16][17]>(smem + 2048 + 2176);      // [8][16][17]  h' tiles
+  float (*zp)[16][16] = reinterpret_cast<float (*)[16][16]>(smem + 2048 + 2176 + 2176);   // [8][16][16] partial logits
+  float (*dzs)[17] = reinterpret_cast<float (*)[17]>(smem + 2048 + 2176 + 2176 + 2048);   // [16][17]  dz2 of the 16 rows
+  float* part_loss = smem + 2048 + 2176 + 2176 + 2048 + 272;                              // [4]
+  int* part_cnt = reinterpret_cast<int*>(part_loss + 4);                                  // [4]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, g = lane >> 4;
+  const int NT = p.HP >> 4;
+  const bool post = rbl >= NRB;                       // workgroup-uniform
+  const int rb = post ? rbl - NRB : rbl;
+  const int m0 = rb * 16;
+  const int a = p.q & 1, pg = a ^ 1;
+
+  // ---- every load of the workgroup is requested here, before anything waits ----
+  // (1) stage 1: z1 tile = Q - lr G D1, K (batch rows of the previous step) split in two halves over the waves
+  const int kh = wave >= NT ? 1 : 0;                  // wave-uniform
+  const int tile = wave - kh * NT;
+  const bool s1_wave = wave < 2 * NT;
+  const int n0 = tile * 16;
+  constexpr int NB0 = (NRB + 1) / 2, NB1 = NRB - NB0; // 16-row blocks of K per half
+  const int kb0 = kh == 0 ? 0 : NB0;
+  const int nbk = kh == 0 ? NB0 : NB1;
+  const rsrc_t rg = make_rsrc(p.GG + ((size_t)pg * 3 + (post ? 0 : 1)) * PIPE_MAT, PIPE_MAT * 4u);
+  const rsrc_t rd = make_rsrc(p.D1 + (size_t)pg * PIPE_MAT, PIPE_MAT * 4u);
+  // training rows start from Q of this step, accuracy-only rows from z1 of the previous step
+  const rsrc_t rq = make_rsrc(post ? p.Z1 + (size_t)pg * PIPE_MAT : p.Q + (size_t)a * PIPE_MAT, PIPE_MAT * 4u);
+  float ga[NB0][4], db[NB0][4], qv[4];
+#pragma unroll
+  for (int jb = 0; jb < NB0; ++jb) {
+#ifdef PIPE_EXP_NO_S1
+    const bool ok = false;
+#else
+    const bool ok = s1_wave && jb < nbk;
+#endif
+    bld4(rg, ok ? pipe_frag(rb, kb0 + jb, lane) * 4u : kOOB, ga[jb]);
+    bld4(rd, ok ? pipe_frag(tile, kb0 + jb, lane) * 4u : kOOB, db[jb]);
+  }
+  bld4(rq, kh == 0 ? pipe_frag(rb, tile, lane) * 4u : kOOB, qv);
+  // (2) label of (row, class) and class of the row for the softmax threads, the step number for the log record.
+  //     Buffer loads without a branch around them: a load inside divergent control flow made the compiler wait for
+  //     EVERY outstanding load (vmcnt(0)) in front of the stage-1 MFMAs.
+  const int srow = tid >> 4;                          // threads [0,256): row srow, class fr
+  const int lslot = post ? ((p.q + PIPE_SLOTS - 1) & (PIPE_SLOTS - 1)) : p.q;
+  const rsrc_t rlab = make_rsrc(p.labg + lslot * PIPE_LABG_SLOT, PIPE_LABG_SLOT * 4u);
+  const rsrc_t rli = make_rsrc(p.labi + lslot * PIPE_ROWS, PIPE_ROWS * 4u);
+  const rsrc_t rctr = make_rsrc(p.ctr, 16u);
+  const float lab = bld(rlab, tid < 256 ? (unsigned)(fr * PIPE_ROWS + m0 + srow) * 4u : kOOB);
+  const int lab_class = bldi(rli, tid < 256 ? (unsigned)(m0 + srow) * 4u : kOOB);
+  const int ls = bldi(rctr, (unsigned)(2 * a + 1) * 4u);
+  // (3) the output layer of this step
+  const unsigned blk4 = (unsigned)p.HP * 64u;
+  const rsrc_t rw2 = make_rsrc(p.W2m + (size_t)pg * p.HP * 16, blk4);
+  const rsrc_t rp2 = make_rsrc(p.P2 + (size_t)pg * 8 * p.HP * 16, 8u * blk4);
+  const int e0 = tid, e1i = tid + 1024;
+  PipeW2Loads<NRB> w2l0, w2l1;
+  pipe_w2_request<NRB>(w2l0, rw2, rp2, (unsigned)e0 * 4u, blk4);
+  pipe_w2_request<NRB>(w2l1, rw2, rp2, e1i < p.HP * 16 ? (unsigned)e1i * 4u : kOOB, blk4);
+  // nothing moves across this line: the scheduler otherwise sinks the operand loads next to their MFMAs and the
+  // workgroup pays one cold round trip per 16-row block instead of one in all
+  __builtin_amdgcn_sched_barrier(0);
+  PIPE_STAMP(1);
+
+  // ---- stage 1 ----
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if (s1_wave) {
+#pragma unroll
+    for (int jb = 0; jb < NB0; ++jb) {
+      acc0 = MFMA16(ga[jb][0], db[jb][0], acc0);
+      acc1 = MFMA16(ga[jb][1], db[jb][1], acc1);
+      acc0 = MFMA16(ga[jb][2], db[jb][2], acc0);
+      acc1 = MFMA16(ga[jb][3], db[jb][3], acc1);
+    }
+    if (kh == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[tile][r][lane] = acc0[r] + acc1[r];
+    }
+  }
+  {
+    const float w2a = pipe_w2_value<NRB>(w2l0, p.lr), w2b = pipe_w2_value<NRB>(w2l1, p.lr);
+    if (e0 < p.HP * 16) w2s[e0 >> 4][e0 & 15] = w2a;
+    if (e1i < p.HP * 16) w2s[e1i >> 4][e1i & 15] = w2b;
+    if (rbl == 0) {                                    // one workgroup keeps W2'(s) for the next launch
+      float* out = p.W2m + (size_t)a * p.HP * 16;
+      if (e0 < p.HP * 16) out[e0] = w2a;
+      if (e1i < p.HP * 16) out[e1i] = w2b;
+    }
+  }
+  PIPE_STAMP(2);
+  __syncthreads();
+  PIPE_STAMP(3);
+  float hreg[4] = {0.f, 0.f, 0.f, 0.f};
+  const int col = n0 + fr;
+  if (kh == 0) {
+    float zv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      zv[r] = qv[r] - p.lr * ((acc0[r] + acc1[r]) + part[tile][r][lane]);
+      // column Hd of h' is the constant 1 that carries b2; columns beyond it do not exist
+      hreg[r] = col < p.Hd ? fmaxf(zv[r], 0.f) : (col == p.Hd ? 1.f : 0.f);
+      hs[tile][4 * g + r][fr] = hreg[r];
+    }
+    // ---- stage 2: partial logits of the tile's 16 hidden columns (a wave reads back only its own h tile: LDS
+    //      operations of one wave execute in order, no workgroup barrier needed) ----
+    __builtin_amdgcn_wave_barrier();
+    f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+    z0 = MFMA16(hs[tile][fr][g], w2s[n0 + g][fr], z0);
+    z1 = MFMA16(hs[tile][fr][4 + g], w2s[n0 + 4 + g][fr], z1);
+    z0 = MFMA16(hs[tile][fr][8 + g], w2s[n0 + 8 + g][fr], z0);
+    z1 = MFMA16(hs[tile][fr][12 + g], w2s[n0 + 12 + g][fr], z1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zp[tile][4 * g + r][fr] = z0[r] + z1[r];
+    if (!post) {                                       // z1 of this batch: the next launch's accuracy-only rows start from it
+      const f32x4 z4 = {zv[0], zv[1], zv[2], zv[3]};
+      *reinterpret_cast<f32x4*>(p.Z1 + (size_t)a * PIPE_MAT + pipe_frag(rb, tile, lane)) = z4;
+    }
+  }
+  __syncthreads();
+  PIPE_STAMP(5);
+  // ---- stage 3: loss, accuracy, dz2 of the 16 rows (16 lanes per row) ----
+  if (tid < 256) {
+    float z = 0.f;
+    for (int t = 0; t < NT; ++t) z += zp[t][srow][fr];
+    const int row = m0 + srow;
+    const bool row_ok = row < p.B;
+    float loss = 0.f, dz = 0.f;
+    int hit = 0;
+#ifdef PIPE_EXP_NO_SOFTMAX
+    dz = z * 1e-9f + lab;
+    hit = lab_class;
+#else
+    pipe_row_head(z, lab, lab_class, fr < p.C, row_ok && !post, fr, p.loss_mode, p.inv_b, loss, hit, dz);
+#endif
+    dzs[srow][fr] = dz;
+    float loss_acc = (fr == 0 && row_ok) ? loss : 0.f;
+    int cnt = (fr == 0 && row_ok) ? hit : 0;
+    loss_acc += __shfl_xor(loss_acc, 16);
+    loss_acc += __shfl_xor(loss_acc, 32);
+    cnt += __shfl_xor(cnt, 16);
+    cnt += __shfl_xor(cnt, 32);
+    if (lane == 0) {
+      part_loss[wave] = loss_acc;
+      part_cnt[wave] = cnt;
+    }
+  }
+  __syncthreads();
+  PIPE_STAMP(6);
+  if (tid == 0) {
+    int* rec = p.wlog + (size_t)DTF_WLOG_INTS * (ls % p.log_cap);
+    const int c = (part_cnt[0] + part_cnt[1]) + (part_cnt[2] + part_cnt[3]);
+    if (post) {
+      rec[36 + rb] = c;
+    } else {
+      rec[4 + rb] = __float_as_int((part_loss[0] + part_loss[1]) + (part_loss[2] + part_loss[3]));
+      rec[20 + rb] = c;
+    }
+  }
+  if (post || kh != 0) return;
+  // ---- stage 4: dz1 tile = (dz2 W2^T) masked by the ReLU, kept for the next launch ----
+  {
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    d0 = MFMA16(dzs[fr][g], w2s[n0 + fr][g], d0);
+    d1 = MFMA16(dzs[fr][4 + g], w2s[n0 + fr][4 + g], d1);
+    d0 = MFMA16(dzs[fr][8 + g], w2s[n0 + fr][8 + g], d0);
+    d1 = MFMA16(dzs[fr][12 + g], w2s[n0 + fr][12 + g], d1);
+    f32x4 d4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d4[r] = (col < p.Hd && hreg[r] > 0.f) ? d0[r] + d1[r] : 0.f;
+    // B-operand layout: k = batch row m0 + 4g + r, n = col: the four values of a lane are one fragment entry
+    *reinterpret_cast<f32x4*>(p.D1 + (size_t)a * PIPE_MAT + pipe_frag(tile, rb, lane)) = d4;
+  }
+  // ---- stage 5: this row block's share of the output layer's gradient, h'^T dz2 ----
+  {
+    f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
+    u0 = MFMA16(hs[tile][g][fr], dzs[g][fr], u0);
+    u1 = MFMA16(hs[tile][4 + g][fr], dzs[4 + g][fr], u1);
+    u0 = MFMA16(hs[tile][8 + g][fr], dzs[8 + g][fr], u0);
+    u1 = MFMA16(hs[tile][12 + g][fr], dzs[12 + g][fr], u1);
+    float* out = p.P2 + (((size_t)a * 8 + rb) * p.HP + n0) * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(4 * g + r) * 16 + fr] = u0[r] + u1[r];
+  }
+  PIPE_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int NRB>
+__global__ __launch_bounds__(1024) void pipe_step_kernel(DtfPipeArgs p) {
+  __shared__ float smem[9216];
+  const PipeDims d = pipe_dims(p, NRB);
+  int b = blockIdx.x;
+  PIPE_STAMP(0);
+  if (b < d.nL) { pipe_role_l<NRB>(p, b, smem); return; }
+  b -= d.nL;
+  if (b < d.nW) { pipe_role_w<NRB>(p, b); return; }
+  b -= d.nW;
+  if (b < d.nQ) { pipe_role_q<NRB>(p, b, smem); return; }
+  b -= d.nQ;
+  if (b < d.nG) { pipe_role_g<NRB>(p, b, smem); return; }
+  b -= d.nG;
+  if (b < d.nT) { pipe_role_t(p, b); return; }
+  b -= d.nT;
+  if (b < d.nF) pipe_role_f<NRB>(p);
+}
+
+// Start of a run of steps: both generations of the working copies from the flat parameter buffer, no pending
+// gradient (D1, P2 zero), counters of the first step.
+__global__ __launch_bounds__(1024) void pipe_prime_kernel(DtfPipeArgs p) {
+  const long long nWm = (long long)p.KAp * p.HP, nW2 = (long long)p.HP * 16, nD1 = PIPE_MAT, nP2 = 8ll * p.HP * 16;
+  const long long total = 2 * (nWm + nW2 + nD1 + nP2);
+  for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < total; i += (long long)gridDim.x * 1024) {
+    long long e = i;
+    if (e < 2 * nWm) {
+      const long long w = e % nWm;
+      const int k = (int)(w / p.HP), c = (int)(w - (long long)k * p.HP);
+      float v = 0.f;
+      if (c < p.Hd) {
+        if (k < p.In) v = p.W1[(size_t)k * p.Hd + c];
+        else if (k == p.In) v = p.b1[c];
+      }
+      p.Wm[e] = v;
+      continue;
+    }
+    e -= 2 * nWm;
+    if (e < 2 * nW2) {
+      const long long w = e % nW2;
+      const int k = (int)(w >> 4), c = (int)(w & 15);
+      float v = 0.f;
+      if (c < p.C) {
+        if (k < p.Hd) v = p.W2[(size_t)k * p.C + c];
+        else if (k == p.Hd) v = p.b2[c];
+      }
+      p.W2m[e] = v;
+      continue;
+    }
+    e -= 2 * nW2;
+    if (e < 2 * nD1) { p.D1[e] = 0.f; continue; }
+    e -= 2 * nD1;
+    p.P2[e] = 0.f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    // p.q is the slot of the launch BEFORE the first step: that step reads generation (q + 1) & 1 of the counters
+    p.ctr[2 * ((p.q & 1) ^ 1) + threadIdx.x] = p.tail.state[threadIdx.x];
+  }
+}
+
+static int pipe_validate(const DtfPipeArgs* a) {
+  if (!a || !a->X || !a->labels || !a->Xa || !a->labg || !a->ridx || !a->Wm || !a->W2m || !a->Q || !a->GG || !a->D1 || !a->P2 ||
+      !a->ctr || !a->Z1 || !a->labi || !a->W1 || !a->b1 || !a->W2 || !a->b2 || !a->wlog || !a->tail.state)
+    return DTF_ERR_ARG;
+  if (a->In <= 0 || (a->In & 3) || a->Hd <= 0 || a->Hd > 127 || a->C <= 0 || a->C > 16 || a->B <= 0 || a->B > PIPE_ROWS)
+    return DTF_ERR_SHAPE;
+  if (a->R != a->B && a->R != 2 * a->B) return DTF_ERR_SHAPE;
+  if (a->HP != ((a->Hd + 1 + 15) & ~15) || a->KAp != ((a->In + 1 + 15) & ~15) || a->ldxa != a->KAp) return DTF_ERR_SHAPE;
+  if ((a->KAp >> 4) + dtf_cdiv(a->B, 16) > 64) return DTF_ERR_SHAPE;           // split-K of role Q: 16 waves x 4 chunks
+  if (a->q < 0 || a->q >= PIPE_SLOTS || a->ldx < a->In || (a->ldx & 3) || a->log_cap <= 0 || a->ridx_len < 2 * a->B)
+    return DTF_ERR_SHAPE;
+  if (!dtf_aligned16(a->X) || !dtf_aligned16(a->Xa) || !dtf_aligned16(a->GG) || !dtf_aligned16(a->D1) || !dtf_aligned16(a->Q) || !dtf_aligned16(a->Z1)) return DTF_ERR_ALIGN;
+  if ((uint64_t)PIPE_ROWS * a->ldxa * 4u >= 0xFFFFFFF0u || (uint64_t)a->KAp * a->HP * 4u >= 0xFFFFFFF0u) return DTF_ERR_SHAPE;
+  if (a->tail.n_train <= 0 || !a->tail.enable) return DTF_ERR_SHAPE;
+  if (a->roles <= 0 || a->roles > 63) return DTF_ERR_ARG;
+  if (a->flush && (a->roles & ~(PIPE_ROLE_W | PIPE_ROLE_F))) return DTF_ERR_ARG;
+  if (a->prime && (a->flush || a->roles != PIPE_ROLE_Q)) return DTF_ERR_ARG;
+  return DTF_OK;
+}
+
+template <int NRB>
+static void pipe_launch(const DtfPipeArgs& a, hipStream_t s) {
+  const PipeDims d = pipe_dims(a, NRB);
+  const int nblk = d.nL + d.nQ + d.nG + d.nW + d.nT + d.nF;
+  hipLaunchKernelGGL((pipe_step_kernel<NRB>), dim3(nblk), dim3(1024), 0, s, a);
+}
+
+static int pipe_launch_any(const DtfPipeArgs& a, hipStream_t s) {
+  const int nrb = dtf_cdiv(a.B, 16);
+  if (nrb <= 2) pipe_launch<2>(a, s);
+  else if (nrb <= 4) pipe_launch<4>(a, s);
+  else if (nrb <= 7) pipe_launch<7>(a, s);
+  else pipe_launch<8>(a, s);
+  return dtf_check_launch();
+}
+
+// One step: every role.  `a->q` = slot of the step.
+DTF_EXPORT int dtf_pipe_step(const DtfPipeArgs* a, hipStream_t s) {
+  const int rc = pipe_validate(a);
+  if (rc != DTF_OK) return rc;
+  if (a->flush || a->prime || a->roles != (PIPE_ROLE_L | PIPE_ROLE_Q | PIPE_ROLE_G | PIPE_ROLE_W | PIPE_ROLE_T)) return DTF_ERR_ARG;
+  return pipe_launch_any(*a, s);
+}
+
+// Start of a run whose first step has slot (a->q + 1) & 7: working copies from the flat buffer, then Q of that step.
+DTF_EXPORT int dtf_pipe_prime(const DtfPipeArgs* a, hipStream_t s) {
+  const int rc = pipe_validate(a);
+  if (rc != DTF_OK) return rc;
+  if (a->flush || !a->prime || a->roles != PIPE_ROLE_Q) return DTF_ERR_ARG;
+  const long long total = 2ll * ((long long)a->KAp * a->HP + (long long)a->HP * 16 + (long long)PIPE_MAT + 8ll * a->HP * 16);
+  hipLaunchKernelGGL(pipe_prime_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, *a);
+  const int rc2 = dtf_check_launch();
+  if (rc2 != DTF_OK) return rc2;
+  return pipe_launch_any(*a, s);
+}
+
+// End of a run whose last step had slot (a->q - 1) & 7: the parameters after that step into the flat buffer.
+DTF_EXPORT int dtf_pipe_flush(const DtfPipeArgs* a, hipStream_t s) {
+  const int rc = pipe_validate(a);
+  if (rc != DTF_OK) return rc;
+  if (!a->flush || a->prime || a->roles != (PIPE_ROLE_W | PIPE_ROLE_F)) return DTF_ERR_ARG;
+  return pipe_launch_any(*a, s);
+}
+
+// Measurement only (tools/pipe_probe.py): any subset of the step roles in one launch, results meaningless.
+DTF_EXPORT int dtf_pipe_launch_roles(const DtfPipeArgs* a, hipStream_t s) {
+  const int rc = pipe_validate(a);
+  if (rc != DTF_OK) return rc;
+  return pipe_launch_any(*a, s);
+}

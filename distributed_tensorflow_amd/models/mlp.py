@@ -109,11 +109,23 @@ class MLPProgram:
                              "is outside the two-launch step's range (one hidden layer <= 128 wide, batch <= 128, <= 16 "
                              "classes): using the general three-launch sequence; multi-worker sync then aggregates through "
                              "RCCL instead of the peer exchange inside the backward launch\n")
+        # One worker with SGD in the step: the one-launch pipelined step (csrc/kernels/mlp_pipe.hip), whose dependent
+        # path works on products with the weights of two steps ago plus Gram-matrix corrections; DTF_PIPELINED_STEP=0
+        # keeps the two-launch step.
+        self.pipe = (self.fused2 and self.fused and os.environ.get("DTF_PIPELINED_STEP", "1") != "0"
+                     and ops.pipe_eligible(in_dim, self.hidden, classes, batch)
+                     and dataset.n >= 8 * batch)        # a launch looks three batches ahead within two epochs
+        if self.pipe:
+            self.fused2 = False
         # Per-step buffers rotate over P slots (slot of a step = local step % P).  P = 2: the tail of step s
         # writes the rows of step s+1 while step s is still being read.  The two-launch step also keeps the
-        # gathered batch of step s-1 (its accuracy-only rows), hence P = 3.
-        self.P = ops.MLP2_SLOTS if self.fused2 else 2
+        # gathered batch of step s-1 (its accuracy-only rows), hence P = 3.  The pipelined step reads the batches
+        # of steps s-1 .. s+2 while it gathers the one of step s+3: P = 8.
+        self.P = ops._lib.PIPE_SLOTS if self.pipe else ops.MLP2_SLOTS if self.fused2 else 2
         self.ridx = torch.zeros((self.P, max(128, (2 * batch + 15) // 16 * 16)), dtype=i32, device=dev)
+        if self.pipe:
+            self.pbuf = ops.PipeBuffers(in_dim, self.hidden[0], dev)
+            self.wlog = torch.zeros((log_capacity, ops._lib.WLOG_INTS), dtype=i32, device=dev)
         if self.fused2:
             r16 = (self.R + 15) // 16
             self.xg = torch.zeros((self.P, ops.MLP2_ROWS, in_dim), dtype=f32, device=dev)
@@ -167,6 +179,18 @@ class MLPProgram:
         items = self._wgrad_items(q)
         wgrad = ops.build_wgrad_args(items, lr=st.lr if self.fused else None, tail=self._tail(q))
         out = {"head": head, "wgrad": wgrad, "items": items}
+        if self.pipe:
+            L = ops._lib
+            tail = ops.make_tail(st.state, perm=self.data.perm, batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
+
+            def pack(slot, roles, flush=False, prime=False):
+                return ops.build_pipe_args(self.data.images, self.data.labels, self.pbuf, self.ridx, st.var("hid_w"),
+                                           st.var("hid_b"), st.var("sm_w"), st.var("sm_b"), self.wlog, self.B, self.R,
+                                           self.loss_mode, slot % self.P, tail, st.lr, roles, flush, prime)
+            # a run whose first step has slot q starts with pipe_prime[q]; one whose last step had slot q ends with pipe_flush[q]
+            out["pipe_step"] = pack(q, L.PIPE_ROLE_L | L.PIPE_ROLE_Q | L.PIPE_ROLE_G | L.PIPE_ROLE_W | L.PIPE_ROLE_T)
+            out["pipe_prime"] = pack(q - 1, L.PIPE_ROLE_Q, prime=True)
+            out["pipe_flush"] = pack(q + 1, L.PIPE_ROLE_W | L.PIPE_ROLE_F, flush=True)
         if self.fused2:
             tail = ops.make_tail(st.state, perm=self.data.perm, batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
             if self.fused or self.async_push is not None or self.shard_exchange is not None:
@@ -247,6 +271,10 @@ class MLPProgram:
         """Select the rows of the first batch (runs once, before the first step)."""
         self.steps_enqueued = self.state.local_step()
         q = self.steps_enqueued % self.P
+        if self.pipe:
+            self._start_pipe(q)
+            self._started = True
+            return
         self.data.prepare(self.steps_enqueued, 0, self.B)
         if self.is_cuda:
             t = ops.make_tail(self.state.state, ridx_cur=None, ridx_next=self.ridx[q], perm=self.data.perm, batch=self.B,
@@ -262,6 +290,52 @@ class MLPProgram:
         else:
             self._tail_cpu(q, init_only=True)
         self._started = True
+
+    def _rows_of_step(self, step: int) -> torch.Tensor:
+        """Dataset rows of the batch of 0-based local step ``step`` (its epoch's permutation must be resident)."""
+        pos = torch.arange(step * self.B, (step + 1) * self.B, dtype=torch.int64, device=self.device)
+        epoch, off = pos // self.data.n, pos % self.data.n
+        if self.data.perm is None:
+            return off
+        return self.data.perm[(epoch & 1), off].long()
+
+    def _start_pipe(self, q: int) -> None:
+        """The pipelined step finds the batches of its first three steps gathered (a step gathers the batch three
+        steps ahead, through the row indices selected one step earlier still) and, as the accuracy-only rows of the
+        first step, the first batch again."""
+        ls, B, C, b = self.steps_enqueued, self.B, self.C, self.pbuf
+        in_dim = self.data.images.shape[1]
+        self.data.prepare(ls, 3, B)
+        prev = None
+        for j in range(4):
+            slot = (q + j) % self.P
+            rows = self._rows_of_step(ls + j)
+            self.ridx[slot][:B] = rows.to(torch.int32)
+            self.ridx[slot][B:2 * B] = (rows if prev is None else prev).to(torch.int32)
+            prev = rows
+            if j == 3:
+                break                                   # the first step gathers this batch itself
+            lab = self.data.labels.index_select(0, rows)
+            b.xa[slot].zero_()
+            b.xa[slot][:B, :in_dim].copy_(self.data.images.index_select(0, rows))
+            b.xa[slot][:B, in_dim] = 1.0
+            b.labg[slot].zero_()
+            b.labg[slot][:C, :B].copy_(lab.t())
+            b.labi[slot].zero_()
+            b.labi[slot][:B] = lab.argmax(1).to(torch.int32)     # first maximal entry, as tf.argmax
+        before = (q - 1) % self.P
+        b.xa[before].copy_(b.xa[q])
+        b.labg[before].copy_(b.labg[q])
+        b.labi[before].copy_(b.labi[q])
+
+    def _enqueue_block(self, n: int) -> None:
+        """``n`` pipelined steps: prime launch (Q of the first step from the flat parameters), one launch per step,
+        flush launch (parameters of the last step into the flat buffer)."""
+        q0 = self.steps_enqueued % self.P
+        ops.pipe_prime(self._args[q0]["pipe_prime"])
+        for i in range(n):
+            ops.pipe_step(self._args[(q0 + i) % self.P]["pipe_step"])
+        ops.pipe_flush(self._args[(q0 + n - 1) % self.P]["pipe_flush"])
 
     def _compute_schedule(self, q: int):
         """The whole compute part of a step (forward, head, backward, weight gradients + tail) as one
@@ -301,6 +375,10 @@ class MLPProgram:
         """Enqueue one full training step on the current stream (no host synchronisation)."""
         q = self.steps_enqueued % self.P
         st, rows = self.state, self.ridx[q]
+        if self.pipe:
+            self._enqueue_block(1)
+            self.steps_enqueued += 1
+            return
         if self.is_cuda and not self.wide_head:
             self._compute_schedule(q).run()
         else:
@@ -365,8 +443,11 @@ class MLPProgram:
             g = torch.cuda.CUDAGraph()
             with _no_gc():
                 with torch.cuda.graph(g):
-                    for _ in range(n):
-                        self.enqueue_step()
+                    if self.pipe:
+                        self._enqueue_block(n)
+                    else:
+                        for _ in range(n):
+                            self.enqueue_step()
             self.steps_enqueued = saved   # capture enqueues nothing
             self._graphs[key] = g
         return g
@@ -376,7 +457,7 @@ class MLPProgram:
         then the rest.  The rest is ONE graph of exactly that many steps when such a graph exists already (or
         ``exact_tail`` asks for it: ``prepare_graphs``), so that a prepared run of 20 steps is one replay; otherwise
         powers of two, which bounds the number of different graphs an unprepared caller can make us capture."""
-        limit = self.data.max_steps_per_launch(self.B)
+        limit = max(1, self.data.max_steps_per_launch(self.B) - self._lookahead())
         graph_steps = max(2, min(graph_steps, limit) & ~1)
         remaining, at = n_steps, self.steps_enqueued
         while remaining > 0:
@@ -392,6 +473,10 @@ class MLPProgram:
             yield n
             remaining -= n
             at += n
+
+    def _lookahead(self) -> int:
+        """Steps beyond the next one whose rows a step already selects (the pipelined step selects four ahead)."""
+        return 3 if self.pipe else 0
 
     def prepare_graphs(self, n_steps: int, graph_steps: int = 64, start_offset: int = 0) -> None:
         """Capture and instantiate, without launching anything, the hipGraphs a later ``run(n_steps, graph_steps)``
@@ -415,8 +500,8 @@ class MLPProgram:
 
     def native_launch_ok(self) -> bool:
         """Steps of this program can be launched many at a time by the native executor (no Python between them)."""
-        return (self.is_cuda and not self.wide_head and self.after_compute is None and self.phase_period == 1
-                and hasattr(self, "schedule_tail_entries"))
+        return (self.is_cuda and not self.wide_head and not self.pipe and self.after_compute is None
+                and self.phase_period == 1 and hasattr(self, "schedule_tail_entries"))
 
     def run_native(self, n_steps: int) -> None:
         """``n_steps`` steps enqueued by ONE native call (``dtf_run_schedule_steps``): the device starts a few
@@ -445,7 +530,7 @@ class MLPProgram:
         if not self._started:
             self.start()
         for n in list(self._launch_sizes(n_steps, graph_steps)):
-            self.data.prepare(self.steps_enqueued, n, self.B)
+            self.data.prepare(self.steps_enqueued, n + self._lookahead(), self.B)
             if n >= 2:
                 self._graph_for(n).replay()
                 self.steps_enqueued += n
@@ -473,7 +558,7 @@ class MLPProgram:
     def _log_host(self) -> torch.Tensor:
         """The log ring on the host as ``[capacity, 4]`` int32 records {loss bits, correct, post, global_step}.
         The two-launch step logs per-row-block partial sums; they are folded here in a fixed order."""
-        if not self.fused2:
+        if not (self.fused2 or self.pipe):
             return self.log.cpu()
         w = self.wlog.cpu()
         nb = (self.R + 15) // 16

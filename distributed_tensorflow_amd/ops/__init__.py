@@ -559,6 +559,84 @@ def mlp2_bwd(args):
     _lib.check(_lib.kernels().dtf_mlp2_bwd(C.byref(args), _lib.stream_handle()), "mlp2_bwd")
 
 
+def pipe_eligible(in_dim, hidden, classes, batch) -> bool:
+    """Shapes the one-launch pipelined step of ``csrc/kernels/mlp_pipe.hip`` covers (the reference network does)."""
+    return (len(hidden) == 1 and hidden[0] <= 127 and classes <= 16 and batch <= 128 and in_dim % 4 == 0
+            and (in_dim + 16) // 16 + (batch + 15) // 16 <= 64)
+
+
+class PipeBuffers:
+    """Working buffers of the pipelined step (two generations each, see ``DtfPipeArgs``)."""
+
+    def __init__(self, in_dim, hd, device):
+        f32, i32 = torch.float32, torch.int32
+        self.HP = (hd + 1 + 15) // 16 * 16
+        self.KAp = (in_dim + 1 + 15) // 16 * 16
+        z = lambda *shape: torch.zeros(shape, dtype=f32, device=device)
+        self.xa = z(_lib.PIPE_SLOTS, 128, self.KAp)
+        self.labg = z(_lib.PIPE_SLOTS, 16, 128)
+        self.wm = z(2, self.KAp, self.HP)
+        self.w2m = z(2, self.HP, 16)
+        # matrices that are only read as MFMA operands are stored per 16x16 tile in fragment order (mlp_pipe.hip)
+        self.q = z(2, 16384)
+        self.z1 = z(2, 16384)
+        self.labi = torch.zeros((_lib.PIPE_SLOTS, 128), dtype=i32, device=device)
+        self.gg = z(2, 3, 16384)
+        self.d1 = z(2, 16384)
+        self.p2 = z(2, 8, self.HP, 16)
+        self.ctr = torch.zeros((2, 2), dtype=i32, device=device)
+
+
+def build_pipe_args(x, labels, bufs, ridx, w1, b1, w2, b2, wlog, batch, rows_total, loss_mode, slot, tail, lr, roles,
+                    flush=False, prime=False):
+    """Argument pack of one launch of the pipelined step: ``roles`` all five step roles (a step at slot ``slot``),
+    only Q (the prime launch, ``slot`` = the slot before the run's first step) or W | F with ``flush`` (the flush
+    launch, ``slot`` = the slot after the run's last step)."""
+    in_dim, hd = w1.shape
+    c = w2.shape[1]
+    if not pipe_eligible(in_dim, [hd], c, batch):
+        raise ValueError("pipelined step: shape outside its range")
+    if rows_total not in (batch, 2 * batch):
+        raise ValueError("pipelined step: rows_total must be B or 2B")
+    if not 0 <= slot < _lib.PIPE_SLOTS:
+        raise ValueError("pipelined step: slot out of range")
+    if x.shape[1] != in_dim or tuple(w2.shape) != (hd, c) or b1.numel() != hd or b2.numel() != c:
+        raise ValueError("pipelined step: parameter shapes do not chain")
+    if labels.shape[1] != c or labels.shape[0] != x.shape[0]:
+        raise ValueError("pipelined step: labels do not match the dataset")
+    if bufs.HP != (hd + 1 + 15) // 16 * 16 or bufs.KAp != (in_dim + 1 + 15) // 16 * 16:
+        raise ValueError("pipelined step: working buffers were sized for another network")
+    if wlog.dim() != 2 or wlog.shape[1] != _lib.WLOG_INTS:
+        raise ValueError("pipelined step: wide log must be [capacity, 64]")
+    if ridx.dim() != 2 or ridx.shape[0] != _lib.PIPE_SLOTS or ridx.shape[1] < 2 * batch:
+        raise ValueError("pipelined step: row index table must be [8, >= 2B]")
+    ts = (x, labels, bufs.xa, bufs.labg, bufs.wm, bufs.w2m, bufs.q, bufs.z1, bufs.gg, bufs.d1, bufs.p2, w1, b1, w2, b2)
+    _same_device(*ts, ridx, wlog, bufs.ctr, bufs.labi)
+    for i, t in enumerate(ts):
+        _f32c(t, f"pipe operand {i}")
+    for name, t in (("ridx", ridx), ("ctr", bufs.ctr), ("wlog", wlog), ("labi", bufs.labi)):
+        _i32c(t, name)
+    return _lib.PipeArgs(X=x.data_ptr(), labels=labels.data_ptr(), Xa=bufs.xa.data_ptr(), labg=bufs.labg.data_ptr(),
+                         ridx=ridx.data_ptr(), Wm=bufs.wm.data_ptr(), W2m=bufs.w2m.data_ptr(), Q=bufs.q.data_ptr(),
+                         Z1=bufs.z1.data_ptr(), labi=bufs.labi.data_ptr(), GG=bufs.gg.data_ptr(), D1=bufs.d1.data_ptr(), P2=bufs.p2.data_ptr(), ctr=bufs.ctr.data_ptr(),
+                         W1=w1.data_ptr(), b1=b1.data_ptr(), W2=w2.data_ptr(), b2=b2.data_ptr(), wlog=wlog.data_ptr(),
+                         In=in_dim, Hd=hd, C=c, B=batch, R=rows_total, HP=bufs.HP, KAp=bufs.KAp, ldxa=bufs.KAp,
+                         ldx=x.stride(0), ridx_len=ridx.shape[1], q=slot, loss_mode=loss_mode, log_cap=wlog.shape[0],
+                         roles=roles, flush=int(flush), prime=int(prime), lr=float(lr), inv_b=1.0 / batch, tail=tail)
+
+
+def pipe_step(args):
+    _lib.check(_lib.kernels().dtf_pipe_step(C.byref(args), _lib.stream_handle()), "pipe_step")
+
+
+def pipe_prime(args):
+    _lib.check(_lib.kernels().dtf_pipe_prime(C.byref(args), _lib.stream_handle()), "pipe_prime")
+
+
+def pipe_flush(args):
+    _lib.check(_lib.kernels().dtf_pipe_flush(C.byref(args), _lib.stream_handle()), "pipe_flush")
+
+
 def step_tail(tail, init_only=False):
     _lib.check(_lib.kernels().dtf_step_tail(C.byref(tail), int(init_only), _lib.stream_handle()), "step_tail")
 

@@ -144,6 +144,21 @@ class Mlp2Args(C.Structure):
                 ("shard", Mlp2Shard)]
 
 
+class PipeArgs(C.Structure):
+    """Mirror of ``DtfPipeArgs``: the one-launch pipelined step (mlp_pipe.hip)."""
+    _fields_ = [("X", C.c_void_p), ("labels", C.c_void_p), ("Xa", C.c_void_p), ("labg", C.c_void_p), ("ridx", C.c_void_p),
+                ("Wm", C.c_void_p), ("W2m", C.c_void_p), ("Q", C.c_void_p), ("Z1", C.c_void_p), ("labi", C.c_void_p),
+                ("GG", C.c_void_p), ("D1", C.c_void_p), ("P2", C.c_void_p), ("ctr", C.c_void_p), ("W1", C.c_void_p),
+                ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("wlog", C.c_void_p), ("In", C.c_int),
+                ("Hd", C.c_int), ("C", C.c_int), ("B", C.c_int), ("R", C.c_int), ("HP", C.c_int), ("KAp", C.c_int),
+                ("ldxa", C.c_int), ("ldx", C.c_int), ("ridx_len", C.c_int), ("q", C.c_int), ("loss_mode", C.c_int),
+                ("log_cap", C.c_int), ("roles", C.c_int), ("flush", C.c_int), ("prime", C.c_int), ("lr", C.c_float),
+                ("inv_b", C.c_float), ("tail", TailArgs)]
+
+
+PIPE_ROLE_L, PIPE_ROLE_Q, PIPE_ROLE_G, PIPE_ROLE_W, PIPE_ROLE_T, PIPE_ROLE_F = 1, 2, 4, 8, 16, 32
+PIPE_SLOTS = 8
+
 OP_SMALL_GEMM, OP_HEAD, OP_WGRAD, OP_TAIL, OP_GEMM_TILED, OP_UPDATE, OP_MLP2_FWD, OP_MLP2_BWD = 1, 2, 3, 4, 5, 6, 7, 8
 OP_SOFTMAX_XENT = 12
 
@@ -207,6 +222,9 @@ def _declare_kernels(lib):
     lib.dtf_gemm_tiled.argtypes = [C.POINTER(GemmArgs), vp]
     lib.dtf_mlp2_fwd.argtypes = [C.POINTER(Mlp2Args), vp]
     lib.dtf_mlp2_bwd.argtypes = [C.POINTER(Mlp2Args), vp]
+    for name in ("dtf_pipe_step", "dtf_pipe_prime", "dtf_pipe_flush", "dtf_pipe_launch_roles"):
+        getattr(lib, name).argtypes = [C.POINTER(PipeArgs), vp]
+        getattr(lib, name).restype = i32
     lib.dtf_run_schedule.argtypes = [C.POINTER(ScheduleEntry), i32, vp]
     lib.dtf_run_schedule_steps.argtypes = [C.POINTER(C.POINTER(ScheduleEntry)), C.POINTER(i32), i32, i32, i32, vp]
     lib.dtf_run_schedule_steps.restype = i32

@@ -119,10 +119,17 @@ def test_gpu_prepared_graphs_are_the_ones_the_run_replays():
     prog_a.run(23, graph_steps=8)
     prog_b.run(23, graph_steps=8)
     assert len(prog_a._graphs) == n_graphs           # the run replays what was prepared and captures nothing
-    assert (7, 2) in prog_a._graphs                  # 23 = 8 + 8 + ONE graph of the remaining 7 steps
+    assert (7, (7 + 16) % prog_a.P) in prog_a._graphs   # 23 = 8 + 8 + ONE graph of the remaining 7 steps
     ra, rb = prog_a.read_log(0, 30), prog_b.read_log(0, 30)
-    assert [r.loss for r in ra] == [r.loss for r in rb]
-    assert torch.equal(st_a.params, st_b.params) and st_a.global_step() == 31
+    assert st_a.global_step() == 31
+    if prog_a.pipe:
+        # the pipelined step materialises the weights at the ends of a replayed graph: runs cut into graphs at other
+        # steps agree to rounding, not bit for bit
+        assert max(abs(x.loss - y.loss) for x, y in zip(ra, rb)) < 1e-5
+        torch.testing.assert_close(st_a.params, st_b.params, rtol=1e-4, atol=1e-5)
+    else:
+        assert [r.loss for r in ra] == [r.loss for r in rb]
+        assert torch.equal(st_a.params, st_b.params)
 
 
 @pytest.mark.gpu
