@@ -252,6 +252,9 @@ def _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer
                    "peer_mapped_allreduce": getattr(engine, "p2p", None) is not None,
                    "peer_mapped_mode": engine.p2p_mode,
                    "peer_exchange_inside_backward_launch": bool(getattr(engine, "p2p_fused", False)) and getattr(engine, "p2p", None) is not None,
+                   "step_program": ("one launch per step, pipelined (mlp_pipe.hip)" if getattr(prog, "pipe", False)
+                                    else "two launches per step (mlp2_fused.hip)" if getattr(prog, "fused2", False)
+                                    else "general launch sequence"),
                    "post_update_accuracy_pass": not args.no_post_update_accuracy,
                    "hip_graph": bool(prog.use_graphs) and not str(getattr(args, "_launch", "")).startswith("native"),
                    "launch": getattr(args, "_launch", None), "params": state.layout.used},

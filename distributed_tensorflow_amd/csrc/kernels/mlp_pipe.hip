@@ -76,6 +76,7 @@ __device__ __forceinline__ float pipe_bld_s(rsrc_t r, unsigned voff, unsigned so
 #define PIPE_ROLE_W 8
 #define PIPE_ROLE_T 16
 #define PIPE_ROLE_F 32
+#define PIPE_ROLE_C 64              // prime launch: working copies from the flat parameters, pending gradients zero
 
 // Operand-layout storage: D1, the Gram matrices, Q and Z1 are only ever read as MFMA operands, so they are stored the
 // way a wave reads them - per 16x16 tile (8 x 8 tiles per matrix) 64 lanes x 4 consecutive values - and a fragment
@@ -88,8 +89,11 @@ __device__ __forceinline__ float pipe_bld_s(rsrc_t r, unsigned voff, unsigned so
 __host__ __device__ __forceinline__ unsigned pipe_frag(int t0, int t1, int lane) { return (unsigned)(((t0 * 8 + t1) * 64 + lane) * 4); }
 
 struct PipeDims {
-  int NT, KT, nL, nQ, nG, nW, nT, nF;
+  int NT, KT, nL, nQ, nG, nW, nT, nF, nC;
 };
+__host__ __device__ __forceinline__ long long pipe_copy_elems(const DtfPipeArgs& p) {
+  return 2ll * ((long long)p.KAp * p.HP + (long long)p.HP * 16 + (long long)PIPE_MAT + 8ll * p.HP * 16);
+}
 __host__ __device__ __forceinline__ PipeDims pipe_dims(const DtfPipeArgs& p, int nrb) {
   PipeDims d;
   const int post = p.R > p.B ? 1 : 0;
@@ -101,6 +105,7 @@ __host__ __device__ __forceinline__ PipeDims pipe_dims(const DtfPipeArgs& p, int
   d.nW = (p.roles & PIPE_ROLE_W) ? (d.KT * d.NT + 15) >> 4 : 0;
   d.nT = (p.roles & PIPE_ROLE_T) ? (p.B + 31) >> 5 : 0;
   d.nF = (p.roles & PIPE_ROLE_F) ? 1 : 0;
+  d.nC = (p.roles & PIPE_ROLE_C) ? (int)((pipe_copy_elems(p) + 4095) / 4096) : 0;
   return d;
 }
 
@@ -145,9 +150,23 @@ __device__ __forceinline__ void pipe_role_q(const DtfPipeArgs& p, int idx, float
     if (c < nX) {
       const unsigned k = (unsigned)(16 * c + 4 * g);
       bld4(rx, (unsigned)(m0 + fr) * (unsigned)p.ldxa * 4u + k * 4u, av[i]);
+      if (p.prime) {
+        // the working copy is being written by role C of this launch: read W1 / b1 of the flat buffer
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[i][j] = bld(rw, (k + j) * hp4 + bcol);
-    } else if (c - nX < NRB && !post) {
+        for (int j = 0; j < 4; ++j) {
+          const int kk = (int)k + j, cc = n0 + fr;
+          float v = 0.f;
+          if (cc < p.Hd) {
+            if (kk < p.In) v = p.W1[(size_t)kk * p.Hd + cc];
+            else if (kk == p.In) v = p.b1[cc];
+          }
+          bv[i][j] = v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[i][j] = bld(rw, (k + j) * hp4 + bcol);
+      }
+    } else if (c - nX < NRB && !p.prime) {       // (prime: no pending gradient)
       scale[i] = -p.lr;
       bld4(rg, pipe_frag(rb, c - nX, lane) * 4u, av[i]);
       bld4(rd, pipe_frag(nt, c - nX, lane) * 4u, bv[i]);
@@ -521,10 +540,12 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
   float hreg[4] = {0.f, 0.f, 0.f, 0.f};
   const int col = n0 + fr;
   if (kh == 0) {
-    float zv[4];
+    float zv[4], pv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pv[r] = part[tile][r][lane];       // all four reads before the first LDS write below
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      zv[r] = qv[r] - p.lr * ((acc0[r] + acc1[r]) + part[tile][r][lane]);
+      zv[r] = qv[r] - p.lr * ((acc0[r] + acc1[r]) + pv[r]);
       // column Hd of h' is the constant 1 that carries b2; columns beyond it do not exist
       hreg[r] = col < p.Hd ? fmaxf(zv[r], 0.f) : (col == p.Hd ? 1.f : 0.f);
       hs[tile][4 * g + r][fr] = hreg[r];
@@ -548,8 +569,12 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
   PIPE_STAMP(5);
   // ---- stage 3: loss, accuracy, dz2 of the 16 rows (16 lanes per row) ----
   if (tid < 256) {
+    float zt[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) zt[t] = zp[t < NT ? t : 0][srow][fr];
     float z = 0.f;
-    for (int t = 0; t < NT; ++t) z += zp[t][srow][fr];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) z += t < NT ? zt[t] : 0.f;
     const int row = m0 + srow;
     const bool row_ok = row < p.B;
     float loss = 0.f, dz = 0.f;
@@ -612,7 +637,49 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
   PIPE_STAMP(7);
 }
 
-// ---------------------------------------------------------------------------------------------------------
+// Role C (prime launch): both generations of the working copies from the flat parameter buffer, no pending gradient
+// (D1, P2 zero), counters of the first step.  Workgroup `cb` handles 4096 elements.
+__device__ __forceinline__ void pipe_role_c(const DtfPipeArgs& p, int cb) {
+  const int nWm = p.KAp * p.HP, nW2 = p.HP * 16, nD1 = PIPE_MAT, nP2 = 8 * p.HP * 16;
+  const int total = 2 * (nWm + nW2 + nD1 + nP2);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    int e = cb * 4096 + u * 1024 + (int)threadIdx.x;
+    if (e >= total) break;
+    if (e < 2 * nWm) {
+      const int w = e >= nWm ? e - nWm : e;
+      const int k = w / p.HP, c = w - k * p.HP;
+      float v = 0.f;
+      if (c < p.Hd) {
+        if (k < p.In) v = p.W1[(size_t)k * p.Hd + c];
+        else if (k == p.In) v = p.b1[c];
+      }
+      p.Wm[e] = v;
+      continue;
+    }
+    e -= 2 * nWm;
+    if (e < 2 * nW2) {
+      const int w = e >= nW2 ? e - nW2 : e;
+      const int k = w >> 4, c = w & 15;
+      float v = 0.f;
+      if (c < p.C) {
+        if (k < p.Hd) v = p.W2[(size_t)k * p.C + c];
+        else if (k == p.Hd) v = p.b2[c];
+      }
+      p.W2m[e] = v;
+      continue;
+    }
+    e -= 2 * nW2;
+    if (e < 2 * nD1) { p.D1[e] = 0.f; continue; }
+    e -= 2 * nD1;
+    p.P2[e] = 0.f;
+  }
+  if (cb == 0 && threadIdx.x < 2) {
+    // p.q is the slot of the launch BEFORE the first step: that step reads generation (q + 1) & 1 of the counters
+    p.ctr[2 * ((p.q & 1) ^ 1) + threadIdx.x] = p.tail.state[threadIdx.x];
+  }
+}
+
 template <int NRB>
 __global__ __launch_bounds__(1024) void pipe_step_kernel(DtfPipeArgs p) {
   __shared__ float smem[9216];
@@ -629,48 +696,9 @@ __global__ __launch_bounds__(1024) void pipe_step_kernel(DtfPipeArgs p) {
   b -= d.nG;
   if (b < d.nT) { pipe_role_t(p, b); return; }
   b -= d.nT;
-  if (b < d.nF) pipe_role_f<NRB>(p);
-}
-
-// Start of a run of steps: both generations of the working copies from the flat parameter buffer, no pending
-// gradient (D1, P2 zero), counters of the first step.
-__global__ __launch_bounds__(1024) void pipe_prime_kernel(DtfPipeArgs p) {
-  const long long nWm = (long long)p.KAp * p.HP, nW2 = (long long)p.HP * 16, nD1 = PIPE_MAT, nP2 = 8ll * p.HP * 16;
-  const long long total = 2 * (nWm + nW2 + nD1 + nP2);
-  for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < total; i += (long long)gridDim.x * 1024) {
-    long long e = i;
-    if (e < 2 * nWm) {
-      const long long w = e % nWm;
-      const int k = (int)(w / p.HP), c = (int)(w - (long long)k * p.HP);
-      float v = 0.f;
-      if (c < p.Hd) {
-        if (k < p.In) v = p.W1[(size_t)k * p.Hd + c];
-        else if (k == p.In) v = p.b1[c];
-      }
-      p.Wm[e] = v;
-      continue;
-    }
-    e -= 2 * nWm;
-    if (e < 2 * nW2) {
-      const long long w = e % nW2;
-      const int k = (int)(w >> 4), c = (int)(w & 15);
-      float v = 0.f;
-      if (c < p.C) {
-        if (k < p.Hd) v = p.W2[(size_t)k * p.C + c];
-        else if (k == p.Hd) v = p.b2[c];
-      }
-      p.W2m[e] = v;
-      continue;
-    }
-    e -= 2 * nW2;
-    if (e < 2 * nD1) { p.D1[e] = 0.f; continue; }
-    e -= 2 * nD1;
-    p.P2[e] = 0.f;
-  }
-  if (blockIdx.x == 0 && threadIdx.x < 2) {
-    // p.q is the slot of the launch BEFORE the first step: that step reads generation (q + 1) & 1 of the counters
-    p.ctr[2 * ((p.q & 1) ^ 1) + threadIdx.x] = p.tail.state[threadIdx.x];
-  }
+  if (b < d.nF) { pipe_role_f<NRB>(p); return; }
+  b -= d.nF;
+  if (b < d.nC) pipe_role_c(p, b);
 }
 
 static int pipe_validate(const DtfPipeArgs* a) {
@@ -687,16 +715,18 @@ static int pipe_validate(const DtfPipeArgs* a) {
   if (!dtf_aligned16(a->X) || !dtf_aligned16(a->Xa) || !dtf_aligned16(a->GG) || !dtf_aligned16(a->D1) || !dtf_aligned16(a->Q) || !dtf_aligned16(a->Z1)) return DTF_ERR_ALIGN;
   if ((uint64_t)PIPE_ROWS * a->ldxa * 4u >= 0xFFFFFFF0u || (uint64_t)a->KAp * a->HP * 4u >= 0xFFFFFFF0u) return DTF_ERR_SHAPE;
   if (a->tail.n_train <= 0 || !a->tail.enable) return DTF_ERR_SHAPE;
-  if (a->roles <= 0 || a->roles > 63) return DTF_ERR_ARG;
+  if (a->roles <= 0 || a->roles > 127) return DTF_ERR_ARG;
   if (a->flush && (a->roles & ~(PIPE_ROLE_W | PIPE_ROLE_F))) return DTF_ERR_ARG;
-  if (a->prime && (a->flush || a->roles != PIPE_ROLE_Q)) return DTF_ERR_ARG;
+  if (a->prime && (a->flush || a->roles != (PIPE_ROLE_Q | PIPE_ROLE_C))) return DTF_ERR_ARG;
+  if ((a->roles & PIPE_ROLE_C) && !a->prime) return DTF_ERR_ARG;
+  if (2ll * ((long long)a->KAp * a->HP + PIPE_MAT + 9ll * a->HP * 16) >= 0x7fffffffll) return DTF_ERR_SHAPE;
   return DTF_OK;
 }
 
 template <int NRB>
 static void pipe_launch(const DtfPipeArgs& a, hipStream_t s) {
   const PipeDims d = pipe_dims(a, NRB);
-  const int nblk = d.nL + d.nQ + d.nG + d.nW + d.nT + d.nF;
+  const int nblk = d.nL + d.nQ + d.nG + d.nW + d.nT + d.nF + d.nC;
   hipLaunchKernelGGL((pipe_step_kernel<NRB>), dim3(nblk), dim3(1024), 0, s, a);
 }
 
@@ -717,15 +747,12 @@ DTF_EXPORT int dtf_pipe_step(const DtfPipeArgs* a, hipStream_t s) {
   return pipe_launch_any(*a, s);
 }
 
-// Start of a run whose first step has slot (a->q + 1) & 7: working copies from the flat buffer, then Q of that step.
+// Start of a run whose first step has slot (a->q + 1) & 7: working copies from the flat buffer and Q of that step
+// (products with the flat parameters themselves), in one launch.
 DTF_EXPORT int dtf_pipe_prime(const DtfPipeArgs* a, hipStream_t s) {
   const int rc = pipe_validate(a);
   if (rc != DTF_OK) return rc;
-  if (a->flush || !a->prime || a->roles != PIPE_ROLE_Q) return DTF_ERR_ARG;
-  const long long total = 2ll * ((long long)a->KAp * a->HP + (long long)a->HP * 16 + (long long)PIPE_MAT + 8ll * a->HP * 16);
-  hipLaunchKernelGGL(pipe_prime_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, *a);
-  const int rc2 = dtf_check_launch();
-  if (rc2 != DTF_OK) return rc2;
+  if (a->flush || !a->prime || a->roles != (PIPE_ROLE_Q | PIPE_ROLE_C)) return DTF_ERR_ARG;
   return pipe_launch_any(*a, s);
 }
 

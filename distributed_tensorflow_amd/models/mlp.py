@@ -189,7 +189,7 @@ class MLPProgram:
                                            self.loss_mode, slot % self.P, tail, st.lr, roles, flush, prime)
             # a run whose first step has slot q starts with pipe_prime[q]; one whose last step had slot q ends with pipe_flush[q]
             out["pipe_step"] = pack(q, L.PIPE_ROLE_L | L.PIPE_ROLE_Q | L.PIPE_ROLE_G | L.PIPE_ROLE_W | L.PIPE_ROLE_T)
-            out["pipe_prime"] = pack(q - 1, L.PIPE_ROLE_Q, prime=True)
+            out["pipe_prime"] = pack(q - 1, L.PIPE_ROLE_Q | L.PIPE_ROLE_C, prime=True)
             out["pipe_flush"] = pack(q + 1, L.PIPE_ROLE_W | L.PIPE_ROLE_F, flush=True)
         if self.fused2:
             tail = ops.make_tail(st.state, perm=self.data.perm, batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
@@ -328,14 +328,17 @@ class MLPProgram:
         b.labg[before].copy_(b.labg[q])
         b.labi[before].copy_(b.labi[q])
 
-    def _enqueue_block(self, n: int) -> None:
-        """``n`` pipelined steps: prime launch (Q of the first step from the flat parameters), one launch per step,
-        flush launch (parameters of the last step into the flat buffer)."""
-        q0 = self.steps_enqueued % self.P
-        ops.pipe_prime(self._args[q0]["pipe_prime"])
-        for i in range(n):
-            ops.pipe_step(self._args[(q0 + i) % self.P]["pipe_step"])
-        ops.pipe_flush(self._args[(q0 + n - 1) % self.P]["pipe_flush"])
+    def _pipe_open(self) -> None:
+        """Prime launch of a run of pipelined steps: working copies and Q of the next step from the flat parameters."""
+        ops.pipe_prime(self._args[self.steps_enqueued % self.P]["pipe_prime"])
+
+    def _pipe_close(self) -> None:
+        """Flush launch: the parameters after the last enqueued step into the flat buffer."""
+        ops.pipe_flush(self._args[(self.steps_enqueued - 1) % self.P]["pipe_flush"])
+
+    def _pipe_step(self) -> None:
+        ops.pipe_step(self._args[self.steps_enqueued % self.P]["pipe_step"])
+        self.steps_enqueued += 1
 
     def _compute_schedule(self, q: int):
         """The whole compute part of a step (forward, head, backward, weight gradients + tail) as one
@@ -376,8 +379,10 @@ class MLPProgram:
         q = self.steps_enqueued % self.P
         st, rows = self.state, self.ridx[q]
         if self.pipe:
-            self._enqueue_block(1)
-            self.steps_enqueued += 1
+            # one step on its own: between prime and flush, so that the flat parameters are current before and after
+            self._pipe_open()
+            self._pipe_step()
+            self._pipe_close()
             return
         if self.is_cuda and not self.wide_head:
             self._compute_schedule(q).run()
@@ -443,11 +448,10 @@ class MLPProgram:
             g = torch.cuda.CUDAGraph()
             with _no_gc():
                 with torch.cuda.graph(g):
-                    if self.pipe:
-                        self._enqueue_block(n)
-                    else:
-                        for _ in range(n):
-                            self.enqueue_step()
+                    for _ in range(n):
+                        # (a graph of pipelined steps holds the step launches only: run() primes before its first
+                        # graph and flushes after its last, the pipeline state carries over between graphs)
+                        self._pipe_step() if self.pipe else self.enqueue_step()
             self.steps_enqueued = saved   # capture enqueues nothing
             self._graphs[key] = g
         return g
@@ -529,13 +533,21 @@ class MLPProgram:
         """Enqueue ``n_steps`` steps; returns without waiting for the device."""
         if not self._started:
             self.start()
+        if n_steps <= 0:
+            return
+        if self.pipe:
+            self._pipe_open()
         for n in list(self._launch_sizes(n_steps, graph_steps)):
             self.data.prepare(self.steps_enqueued, n + self._lookahead(), self.B)
             if n >= 2:
                 self._graph_for(n).replay()
                 self.steps_enqueued += n
+            elif self.pipe:
+                self._pipe_step()
             else:
                 self.enqueue_step()
+        if self.pipe:
+            self._pipe_close()
 
     def read_log(self, first_local_step: int, count: int) -> List[StepRecord]:
         """Records of local steps ``[first, first+count)`` (0-based).  Synchronises with the device."""

@@ -156,7 +156,7 @@ class PipeArgs(C.Structure):
                 ("inv_b", C.c_float), ("tail", TailArgs)]
 
 
-PIPE_ROLE_L, PIPE_ROLE_Q, PIPE_ROLE_G, PIPE_ROLE_W, PIPE_ROLE_T, PIPE_ROLE_F = 1, 2, 4, 8, 16, 32
+PIPE_ROLE_L, PIPE_ROLE_Q, PIPE_ROLE_G, PIPE_ROLE_W, PIPE_ROLE_T, PIPE_ROLE_F, PIPE_ROLE_C = 1, 2, 4, 8, 16, 32, 64
 PIPE_SLOTS = 8
 
 OP_SMALL_GEMM, OP_HEAD, OP_WGRAD, OP_TAIL, OP_GEMM_TILED, OP_UPDATE, OP_MLP2_FWD, OP_MLP2_BWD = 1, 2, 3, 4, 5, 6, 7, 8

@@ -112,6 +112,7 @@ def test_gpu_prepared_graphs_are_the_ones_the_run_replays():
     for prog in (prog_a, prog_b):
         prog.run(7, graph_steps=4)
     before = prog_a.state.global_step()
+    sizes = list(prog_a._launch_sizes(23, 8, exact_tail=True))    # 8 + 8 + 7 (6 + 6 + 6 + 5 when the step looks further ahead)
     prog_a.prepare_graphs(23, graph_steps=8)
     torch.cuda.synchronize()
     assert prog_a.state.global_step() == before and prog_a.steps_enqueued == 7       # nothing ran
@@ -119,7 +120,8 @@ def test_gpu_prepared_graphs_are_the_ones_the_run_replays():
     prog_a.run(23, graph_steps=8)
     prog_b.run(23, graph_steps=8)
     assert len(prog_a._graphs) == n_graphs           # the run replays what was prepared and captures nothing
-    assert (7, (7 + 16) % prog_a.P) in prog_a._graphs   # 23 = 8 + 8 + ONE graph of the remaining 7 steps
+    assert sum(sizes) == 23 and sizes[-1] in (7, 5)
+    assert (sizes[-1], (7 + 23 - sizes[-1]) % prog_a.P) in prog_a._graphs   # the rest of the run is ONE graph of exactly that length
     ra, rb = prog_a.read_log(0, 30), prog_b.read_log(0, 30)
     assert st_a.global_step() == 31
     if prog_a.pipe:
@@ -246,6 +248,8 @@ def test_gpu_two_launch_step_matches_three_launch_step(monkeypatch, hidden, batc
     mode = ops.LOSS_REFERENCE if loss == "reference" else ops.LOSS_STANDARD
     steps = 21
 
+    monkeypatch.setenv("DTF_PIPELINED_STEP", "0")       # this test is about the two-launch step
+
     def make(device, two_launch):
         monkeypatch.setenv("DTF_FUSED_STEP", "1" if two_launch else "0")
         ds, st, prog, _ = _make(device, hidden=(hidden,), batch=batch, lr=0.2, post=post, loss_mode=mode, fused=fused,
@@ -276,10 +280,11 @@ def test_gpu_two_launch_step_matches_three_launch_step(monkeypatch, hidden, batc
 
 
 @pytest.mark.gpu
-def test_gpu_native_multi_step_launch_equals_graph_replay():
+def test_gpu_native_multi_step_launch_equals_graph_replay(monkeypatch):
     """One native call that enqueues every kernel of a run (bench.py's path for short one-worker runs) against the
     hipGraph replay of the same steps: same log, same parameters, bit for bit."""
     from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    monkeypatch.setenv("DTF_PIPELINED_STEP", "0")       # the native launcher drives the two-launch step
     ds = mnist.synthetic_data_sets(train_size=1000, validation_size=200, test_size=300, seed=5)
     out = []
     for native in (True, False):
