@@ -686,16 +686,18 @@ __global__ __launch_bounds__(1024) void pipe_step_kernel(DtfPipeArgs p) {
   const PipeDims d = pipe_dims(p, NRB);
   int b = blockIdx.x;
   PIPE_STAMP(0);
+  // launch order = dispatch order: the roles with the longest dependent chains first (the row workgroups, then the
+  // gather with its index -> row hop), the short product tiles last
   if (b < d.nL) { pipe_role_l<NRB>(p, b, smem); return; }
   b -= d.nL;
+  if (b < d.nT) { pipe_role_t(p, b); return; }
+  b -= d.nT;
   if (b < d.nW) { pipe_role_w<NRB>(p, b); return; }
   b -= d.nW;
   if (b < d.nQ) { pipe_role_q<NRB>(p, b, smem); return; }
   b -= d.nQ;
   if (b < d.nG) { pipe_role_g<NRB>(p, b, smem); return; }
   b -= d.nG;
-  if (b < d.nT) { pipe_role_t(p, b); return; }
-  b -= d.nT;
   if (b < d.nF) { pipe_role_f<NRB>(p); return; }
   b -= d.nF;
   if (b < d.nC) pipe_role_c(p, b);

@@ -19,7 +19,7 @@ from distributed_tensorflow_amd.data.device_dataset import DeviceDataset     # n
 from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state    # noqa: E402
 
 L = ops._lib
-ROLES = {"L": L.PIPE_ROLE_L, "Q": L.PIPE_ROLE_Q, "G": L.PIPE_ROLE_G, "W": L.PIPE_ROLE_W, "T": L.PIPE_ROLE_T}
+ROLES = {"L": L.PIPE_ROLE_L, "Q": L.PIPE_ROLE_Q, "G": L.PIPE_ROLE_G, "W": L.PIPE_ROLE_W, "T": L.PIPE_ROLE_T, "F": L.PIPE_ROLE_F}
 
 
 def main():
