@@ -373,10 +373,6 @@ __device__ __forceinline__ void pipe_w2_request(PipeW2Loads<NRB>& o, rsrc_t rw2,
   o.w = bld(rw2, e4);
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb) o.part[rb] = pipe_bld_s(rp2, e4, (unsigned)rb * blk4);
-#ifdef PIPE_EXP_NO_P2
-#pragma unroll
-  for (int rb = 0; rb < NRB; ++rb) o.part[rb] = 0.f;
-#endif
 }
 template <int NRB>
 __device__ __forceinline__ float pipe_w2_value(const PipeW2Loads<NRB>& o, float lr) {
@@ -476,11 +472,7 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
   float ga[NB0][4], db[NB0][4], qv[4];
 #pragma unroll
   for (int jb = 0; jb < NB0; ++jb) {
-#ifdef PIPE_EXP_NO_S1
-    const bool ok = false;
-#else
     const bool ok = s1_wave && jb < nbk;
-#endif
     bld4(rg, ok ? pipe_frag(rb, kb0 + jb, lane) * 4u : kOOB, ga[jb]);
     bld4(rd, ok ? pipe_frag(tile, kb0 + jb, lane) * 4u : kOOB, db[jb]);
   }
@@ -579,12 +571,7 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
     const bool row_ok = row < p.B;
     float loss = 0.f, dz = 0.f;
     int hit = 0;
-#ifdef PIPE_EXP_NO_SOFTMAX
-    dz = z * 1e-9f + lab;
-    hit = lab_class;
-#else
     pipe_row_head(z, lab, lab_class, fr < p.C, row_ok && !post, fr, p.loss_mode, p.inv_b, loss, hit, dz);
-#endif
     dzs[srow][fr] = dz;
     float loss_acc = (fr == 0 && row_ok) ? loss : 0.f;
     int cnt = (fr == 0 && row_ok) ? hit : 0;
