@@ -47,6 +47,17 @@ def _sync_all(device, world):
         torch.cuda.synchronize()
 
 
+def _stop_clock(t0: float, device, world) -> float:
+    """Closing bracket of a timed region: wait for this rank's device, take the time, THEN meet the other ranks (the
+    result is the maximum over the ranks, so the rendezvous itself - an all-reduce plus its launch, tens of
+    microseconds - does not belong into a run of a few hundred)."""
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _sync_all(device, world)
+    return _max_over_ranks(dt, device, world)
+
+
 def _max_over_ranks(value: float, device, world) -> float:
     if world == 1:
         return value
@@ -83,9 +94,10 @@ def _rccl_probe(engine, rank, world, device):
 def _time_segment(engine, device, world, steps, graph_steps):
     _sync_all(device, world)
     t0 = time.perf_counter()
-    engine.run(steps, graph_steps)
-    _sync_all(device, world)
-    return _max_over_ranks(time.perf_counter() - t0, device, world)
+    engine.run(steps, graph_steps, defer_checks=True)
+    dt = _stop_clock(t0, device, world)
+    engine.run_checks()
+    return dt
 
 
 def _select_p2p_transport(engine, prog, args, rank, world, device, graph_steps):
@@ -161,6 +173,9 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     if want == "native" and not native:
         raise SystemExit("--launch native: needs one GPU worker whose update is inside the step's own launches")
     run = (lambda n: engine.run_native(n)) if native else (lambda n: engine.run(n, graph_steps))
+    # timed segments: the ranks' agreement on the transport's health (a device read-back and a small all-reduce per
+    # run() call) happens after the clock has stopped
+    run_timed = run if native else (lambda n: engine.run(n, graph_steps, defer_checks=True))
     if world == 1 and not force and device.type == "cuda" and prog.use_graphs and args.warmup > 0 and fast and not native:
         # one worker: nothing is decided during the warm-up, so the graphs of the warm-up AND of the timed run are
         # captured before either (capture takes milliseconds of host time during which the GPU would fall idle and
@@ -197,10 +212,9 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
         "hipGraph replay" if prog.use_graphs else "eager")
     _sync_all(device, world)
     t0 = time.perf_counter()
-    run(args.steps)
-    _sync_all(device, world)
-    dt = time.perf_counter() - t0
-    dt = _max_over_ranks(dt, device, world)
+    run_timed(args.steps)
+    dt = _stop_clock(t0, device, world)
+    engine.run_checks()                                     # raises on every rank if any rank's wait for a peer timed out
     gs = state.global_step()
     assert gs == 1 + extra_steps + args.warmup + args.steps, (gs, extra_steps, args.warmup, args.steps)
     last = prog.read_log(prog.steps_enqueued - 1, 1)[0]
@@ -316,8 +330,7 @@ def bench_resnet50_sync(args, rank, world, device):
     _sync_all(device, world)
     t0 = time.perf_counter()
     engine.run(args.steps)
-    _sync_all(device, world)
-    dt = _max_over_ranks(time.perf_counter() - t0, device, world)
+    dt = _stop_clock(t0, device, world)
     last = prog.read_log(prog.steps_enqueued - 1, 1)[0]
     return {
         "metric": METRIC, "value": batch * args.steps * world / dt, "unit": "examples/sec", "n_gpus": world,
@@ -393,8 +406,7 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
     engine.run(args.steps, 64)
     if world > 1 or force:
         engine.sync_params()
-    _sync_all(device, world)
-    dt = _max_over_ranks(time.perf_counter() - t0, device, world)
+    dt = _stop_clock(t0, device, world)
     stale = None
     if hasattr(engine, "staleness_stats"):
         smax, smean = engine.staleness_stats(args.warmup, args.steps)

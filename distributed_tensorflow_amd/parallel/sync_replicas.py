@@ -427,8 +427,19 @@ class SyncReplicasEngine:
         self.program.run_native(n_steps)
         self.updates_applied += n_steps
 
-    def run(self, n_steps: int, graph_steps: int = 64) -> None:
-        """Run ``n_steps`` aggregated updates (each rank contributes as the R/num_workers ratio dictates)."""
+    def run(self, n_steps: int, graph_steps: int = 64, defer_checks: bool = False) -> None:
+        """Run ``n_steps`` aggregated updates (each rank contributes as the R/num_workers ratio dictates).
+
+        After a run over the peer-mapped transports the ranks agree on whether any wait ran into its limit (a flag
+        read back from the device plus a 4-byte all-reduce, i.e. a device synchronisation and a collective per call).
+        ``defer_checks=True`` enqueues the steps only and leaves that to :meth:`run_checks`, which the caller then
+        owes before it uses the result (a benchmark calls it after its clock has stopped)."""
+        if defer_checks and (self.fast or self.general_on_device) and self.p2p is not None:
+            self.program.run(n_steps * (1 if self.fast else self.rounds), graph_steps)
+            self.updates_applied += n_steps
+            self._checks_owed = True
+            return
+        self._checks_owed = False
         if self.fast:
             # the peer-mapped update is an ordinary kernel: steps that use it replay from hipGraphs like the
             # one-rank step; library collectives stay out of captures unless asked for
@@ -478,6 +489,28 @@ class SyncReplicasEngine:
             return
         for _ in range(n_steps):
             self._general_update()
+
+    def run_checks(self) -> None:
+        """The agreement of the ranks that ``run(..., defer_checks=True)`` left out (collective; no-op otherwise)."""
+        if not getattr(self, "_checks_owed", False):
+            return
+        self._checks_owed = False
+        late = self.p2p.timed_out()
+        if self.fast:
+            self._runs_since_check += 1
+            if self.world > 1 and self._runs_since_check >= self._replica_check_every:
+                self._replica_checks_left = max(self._replica_checks_left, 1)
+            if self._replica_checks_left > 0:
+                self._runs_since_check = 0
+                self._check_replicas(late)
+                return
+        if self.world > 1:
+            t = torch.tensor([1 if late else 0], dtype=torch.int32,
+                             device=self.state.device if self.coll.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.coll.group)
+            late = bool(t.item())
+        if late:
+            raise RuntimeError("peer-mapped transport: a wait for a peer ran into its time limit")
 
     @property
     def dropped(self) -> int:
