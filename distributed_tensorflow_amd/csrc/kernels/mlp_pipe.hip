@@ -437,49 +437,50 @@ __device__ __forceinline__ void pipe_row_head(float zsum, float lab, int lab_cla
 
 template <int NRB>
 __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float* smem) {
+  // One wave per 16-column tile of the hidden layer (NT <= 8 waves; the others leave at once).  A wave owns its tile
+  // through every stage - the stage-1 product over ALL previous batch rows, its 16 rows of W2', its partial logits,
+  // its dz1 tile - so the only exchanges between waves are the logits (sum over the tiles) and dz2 (back to the tiles):
+  // two workgroup barriers.  (Splitting K of stage 1 over two waves per tile gains nothing: 7 tiles on 4 SIMDs leave
+  // the busiest matrix pipe with 56 MFMAs either way, and the split costs an LDS exchange and a third barrier.)
   // LDS carve-up (floats)
-  float (*part)[4][64] = reinterpret_cast<float (*)[4][64]>(smem);                    // [8][4][64]   stage-1 partials of the second K half
-  float (*w2s)[17] = reinterpret_cast<float (*)[17]>(smem + 2048);                    // [128][17]    W2'(s)
-  float (*hs)[16][17] = reinterpret_cast<float (*)[16][17]>(smem + 2048 + 2176);      // [8][16][17]  h' tiles
-  float (*zp)[16][16] = reinterpret_cast<float (*)[16][16]>(smem + 2048 + 2176 + 2176);   // [8][16][16] partial logits
-  float (*dzs)[17] = reinterpret_cast<float (*)[17]>(smem + 2048 + 2176 + 2176 + 2048);   // [16][17]  dz2 of the 16 rows
-  float* part_loss = smem + 2048 + 2176 + 2176 + 2048 + 272;                              // [4]
-  int* part_cnt = reinterpret_cast<int*>(part_loss + 4);                                  // [4]
+  float (*w2t)[16][17] = reinterpret_cast<float (*)[16][17]>(smem);                    // [8][16][17]  W2'(s) rows of each tile
+  float (*hs)[16][17] = reinterpret_cast<float (*)[16][17]>(smem + 2176);             // [8][16][17]  h' tiles
+  float (*zp)[16][16] = reinterpret_cast<float (*)[16][16]>(smem + 2176 + 2176);      // [8][16][16]  partial logits
+  float (*dzs)[17] = reinterpret_cast<float (*)[17]>(smem + 2176 + 2176 + 2048);      // [16][17]     dz2 of the 16 rows
+  float* part_loss = smem + 2176 + 2176 + 2048 + 272;                                 // [4]
+  int* part_cnt = reinterpret_cast<int*>(part_loss + 4);                              // [4]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 15, g = lane >> 4;
   const int NT = p.HP >> 4;
+  if (wave >= (NT > 4 ? NT : 4)) return;              // (waves 0..3 also carry the softmax rows)
+  const int fr = lane & 15, g = lane >> 4;
   const bool post = rbl >= NRB;                       // workgroup-uniform
   const int rb = post ? rbl - NRB : rbl;
   const int m0 = rb * 16;
   const int a = p.q & 1, pg = a ^ 1;
-
-  // ---- every load of the workgroup is requested here, before anything waits ----
-  // (1) stage 1: z1 tile = Q - lr G D1, K (batch rows of the previous step) split in two halves over the waves
-  const int kh = wave >= NT ? 1 : 0;                  // wave-uniform
-  const int tile = wave - kh * NT;
-  const bool s1_wave = wave < 2 * NT;
+  const int tile = wave;
+  const bool t_wave = wave < NT;                      // wave-uniform
   const int n0 = tile * 16;
-  constexpr int NB0 = (NRB + 1) / 2, NB1 = NRB - NB0; // 16-row blocks of K per half
-  const int kb0 = kh == 0 ? 0 : NB0;
-  const int nbk = kh == 0 ? NB0 : NB1;
+  const int col = n0 + fr;
+
+  // ---- every load of the wave is requested here, before anything waits ----
+  // (1) stage 1: z1 tile = Q - lr G D1 over the batch rows of the previous step
   const rsrc_t rg = make_rsrc(p.GG + ((size_t)pg * 3 + (post ? 0 : 1)) * PIPE_MAT, PIPE_MAT * 4u);
   const rsrc_t rd = make_rsrc(p.D1 + (size_t)pg * PIPE_MAT, PIPE_MAT * 4u);
   // training rows start from Q of this step, accuracy-only rows from z1 of the previous step
   const rsrc_t rq = make_rsrc(post ? p.Z1 + (size_t)pg * PIPE_MAT : p.Q + (size_t)a * PIPE_MAT, PIPE_MAT * 4u);
-  float ga[NB0][4], db[NB0][4], qv[4];
+  float ga[NRB][4], db[NRB][4], qv[4];
 #pragma unroll
-  for (int jb = 0; jb < NB0; ++jb) {
-    const bool ok = s1_wave && jb < nbk;
-    bld4(rg, ok ? pipe_frag(rb, kb0 + jb, lane) * 4u : kOOB, ga[jb]);
-    bld4(rd, ok ? pipe_frag(tile, kb0 + jb, lane) * 4u : kOOB, db[jb]);
+  for (int jb = 0; jb < NRB; ++jb) {
+    bld4(rg, t_wave ? pipe_frag(rb, jb, lane) * 4u : kOOB, ga[jb]);
+    bld4(rd, t_wave ? pipe_frag(tile, jb, lane) * 4u : kOOB, db[jb]);
   }
-  bld4(rq, kh == 0 ? pipe_frag(rb, tile, lane) * 4u : kOOB, qv);
-  // (2) label of (row, class) and class of the row for the softmax threads, the step number for the log record.
-  //     Buffer loads without a branch around them: a load inside divergent control flow made the compiler wait for
-  //     EVERY outstanding load (vmcnt(0)) in front of the stage-1 MFMAs.
+  bld4(rq, t_wave ? pipe_frag(rb, tile, lane) * 4u : kOOB, qv);
+  // (2) label of (row, class) and class of the row for the softmax threads, the step number for the log record
+  //     (buffer loads, no branch around them: a load inside divergent control flow makes the compiler wait for
+  //     every outstanding load in front of the first MFMA)
   const int srow = tid >> 4;                          // threads [0,256): row srow, class fr
   const int lslot = post ? ((p.q + PIPE_SLOTS - 1) & (PIPE_SLOTS - 1)) : p.q;
   const rsrc_t rlab = make_rsrc(p.labg + lslot * PIPE_LABG_SLOT, PIPE_LABG_SLOT * 4u);
@@ -488,68 +489,59 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
   const float lab = bld(rlab, tid < 256 ? (unsigned)(fr * PIPE_ROWS + m0 + srow) * 4u : kOOB);
   const int lab_class = bldi(rli, tid < 256 ? (unsigned)(m0 + srow) * 4u : kOOB);
   const int ls = bldi(rctr, (unsigned)(2 * a + 1) * 4u);
-  // (3) the output layer of this step
+  // (3) the wave's 16 rows of the output layer of this step, in the B-operand layout of the logits product:
+  //     lane (class fr, g) holds rows n0 + 4j + g, j = 0..3
   const unsigned blk4 = (unsigned)p.HP * 64u;
   const rsrc_t rw2 = make_rsrc(p.W2m + (size_t)pg * p.HP * 16, blk4);
   const rsrc_t rp2 = make_rsrc(p.P2 + (size_t)pg * 8 * p.HP * 16, 8u * blk4);
-  const int e0 = tid, e1i = tid + 1024;
-  PipeW2Loads<NRB> w2l0, w2l1;
-  pipe_w2_request<NRB>(w2l0, rw2, rp2, (unsigned)e0 * 4u, blk4);
-  pipe_w2_request<NRB>(w2l1, rw2, rp2, e1i < p.HP * 16 ? (unsigned)e1i * 4u : kOOB, blk4);
+  PipeW2Loads<NRB> w2l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    pipe_w2_request<NRB>(w2l[j], rw2, rp2, t_wave ? (unsigned)((n0 + 4 * j + g) * 16 + fr) * 4u : kOOB, blk4);
   // nothing moves across this line: the scheduler otherwise sinks the operand loads next to their MFMAs and the
-  // workgroup pays one cold round trip per 16-row block instead of one in all
+  // wave pays one cold round trip per 16-row block instead of one in all
   __builtin_amdgcn_sched_barrier(0);
   PIPE_STAMP(1);
 
   // ---- stage 1 ----
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  if (s1_wave) {
+  float hreg[4] = {0.f, 0.f, 0.f, 0.f}, w2v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (t_wave) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int jb = 0; jb < NB0; ++jb) {
+    for (int jb = 0; jb < NRB; ++jb) {
       acc0 = MFMA16(ga[jb][0], db[jb][0], acc0);
       acc1 = MFMA16(ga[jb][1], db[jb][1], acc1);
       acc0 = MFMA16(ga[jb][2], db[jb][2], acc0);
       acc1 = MFMA16(ga[jb][3], db[jb][3], acc1);
     }
-    if (kh == 1) {
+    // the output layer brought up to date while the matrix pipe works
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part[tile][r][lane] = acc0[r] + acc1[r];
+    for (int j = 0; j < 4; ++j) {
+      w2v[j] = pipe_w2_value<NRB>(w2l[j], p.lr);
+      w2t[tile][4 * j + g][fr] = w2v[j];
     }
-  }
-  {
-    const float w2a = pipe_w2_value<NRB>(w2l0, p.lr), w2b = pipe_w2_value<NRB>(w2l1, p.lr);
-    if (e0 < p.HP * 16) w2s[e0 >> 4][e0 & 15] = w2a;
-    if (e1i < p.HP * 16) w2s[e1i >> 4][e1i & 15] = w2b;
     if (rbl == 0) {                                    // one workgroup keeps W2'(s) for the next launch
       float* out = p.W2m + (size_t)a * p.HP * 16;
-      if (e0 < p.HP * 16) out[e0] = w2a;
-      if (e1i < p.HP * 16) out[e1i] = w2b;
-    }
-  }
-  PIPE_STAMP(2);
-  __syncthreads();
-  PIPE_STAMP(3);
-  float hreg[4] = {0.f, 0.f, 0.f, 0.f};
-  const int col = n0 + fr;
-  if (kh == 0) {
-    float zv[4], pv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pv[r] = part[tile][r][lane];       // all four reads before the first LDS write below
+      for (int j = 0; j < 4; ++j) out[(n0 + 4 * j + g) * 16 + fr] = w2v[j];
+    }
+    PIPE_STAMP(2);
+    float zv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      zv[r] = qv[r] - p.lr * ((acc0[r] + acc1[r]) + pv[r]);
+      zv[r] = qv[r] - p.lr * (acc0[r] + acc1[r]);
       // column Hd of h' is the constant 1 that carries b2; columns beyond it do not exist
       hreg[r] = col < p.Hd ? fmaxf(zv[r], 0.f) : (col == p.Hd ? 1.f : 0.f);
       hs[tile][4 * g + r][fr] = hreg[r];
     }
-    // ---- stage 2: partial logits of the tile's 16 hidden columns (a wave reads back only its own h tile: LDS
+    // ---- stage 2: partial logits of the tile's 16 hidden columns (the wave reads back only its own h tile: LDS
     //      operations of one wave execute in order, no workgroup barrier needed) ----
     __builtin_amdgcn_wave_barrier();
     f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-    z0 = MFMA16(hs[tile][fr][g], w2s[n0 + g][fr], z0);
-    z1 = MFMA16(hs[tile][fr][4 + g], w2s[n0 + 4 + g][fr], z1);
-    z0 = MFMA16(hs[tile][fr][8 + g], w2s[n0 + 8 + g][fr], z0);
-    z1 = MFMA16(hs[tile][fr][12 + g], w2s[n0 + 12 + g][fr], z1);
+    z0 = MFMA16(hs[tile][fr][g], w2v[0], z0);
+    z1 = MFMA16(hs[tile][fr][4 + g], w2v[1], z1);
+    z0 = MFMA16(hs[tile][fr][8 + g], w2v[2], z0);
+    z1 = MFMA16(hs[tile][fr][12 + g], w2v[3], z1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) zp[tile][4 * g + r][fr] = z0[r] + z1[r];
     if (!post) {                                       // z1 of this batch: the next launch's accuracy-only rows start from it
@@ -596,14 +588,14 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
       rec[20 + rb] = c;
     }
   }
-  if (post || kh != 0) return;
+  if (post || !t_wave) return;
   // ---- stage 4: dz1 tile = (dz2 W2^T) masked by the ReLU, kept for the next launch ----
   {
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-    d0 = MFMA16(dzs[fr][g], w2s[n0 + fr][g], d0);
-    d1 = MFMA16(dzs[fr][4 + g], w2s[n0 + fr][4 + g], d1);
-    d0 = MFMA16(dzs[fr][8 + g], w2s[n0 + fr][8 + g], d0);
-    d1 = MFMA16(dzs[fr][12 + g], w2s[n0 + fr][12 + g], d1);
+    d0 = MFMA16(dzs[fr][g], w2t[tile][fr][g], d0);
+    d1 = MFMA16(dzs[fr][4 + g], w2t[tile][fr][4 + g], d1);
+    d0 = MFMA16(dzs[fr][8 + g], w2t[tile][fr][8 + g], d0);
+    d1 = MFMA16(dzs[fr][12 + g], w2t[tile][fr][12 + g], d1);
     f32x4 d4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) d4[r] = (col < p.Hd && hreg[r] > 0.f) ? d0[r] + d1[r] : 0.f;
