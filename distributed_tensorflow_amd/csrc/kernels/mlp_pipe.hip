@@ -67,6 +67,11 @@ __device__ __forceinline__ float pipe_bld_s(rsrc_t r, unsigned voff, unsigned so
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 
+__device__ __forceinline__ void pipe_bld4_s(rsrc_t r, unsigned voff, unsigned soff, float (&v)[4]) {
+  auto t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  v[0] = __uint_as_float(t[0]); v[1] = __uint_as_float(t[1]); v[2] = __uint_as_float(t[2]); v[3] = __uint_as_float(t[3]);
+}
+
 #define PIPE_SLOTS 8
 #define PIPE_ROWS 128
 #define PIPE_LABG_SLOT (16 * PIPE_ROWS)
@@ -85,7 +90,12 @@ __device__ __forceinline__ float pipe_bld_s(rsrc_t r, unsigned voff, unsigned so
 //   B operand (D1: k = batch row, n = hidden column):   tile (n / 16, k / 16), lane = ((k % 16) / 4) * 16 + n % 16, e = k % 4
 //   A operand (Gram: i = row, k = column):              tile (i / 16, k / 16), lane = ((k % 16) / 4) * 16 + i % 16, e = k % 4
 //   C layout  (Q, Z1: MFMA result, row i, column n):    tile (i / 16, n / 16), lane = ((i % 16) / 4) * 16 + n % 16, e = i % 4
+//   output layer (W2m, P2: row k = hidden index, column c = class): per 16 rows 64 lanes x 4 values,
+//                                                        lane = ((k % 16) / 4) * 16 + c, e = k % 4
+//     = the MFMA result layout of h'^T dz2 (what a row workgroup produces) and, with MFMA step j taking k = 4g + j,
+//       the B-operand layout of the logits product (what the next launch's row workgroups consume): 16-byte loads
 #define PIPE_MAT 16384                    // floats per operand-layout matrix (8 x 8 tiles x 256)
+__host__ __device__ __forceinline__ int pipe_w2_off(int k, int c) { return ((k >> 4) * 64 + ((k & 15) >> 2) * 16 + c) * 4 + (k & 3); }
 __host__ __device__ __forceinline__ unsigned pipe_frag(int t0, int t1, int lane) { return (unsigned)(((t0 * 8 + t1) * 64 + lane) * 4); }
 
 struct PipeDims {
@@ -103,7 +113,7 @@ __host__ __device__ __forceinline__ PipeDims pipe_dims(const DtfPipeArgs& p, int
   d.nQ = (p.roles & PIPE_ROLE_Q) ? nrb * (1 + (p.prime ? post : 0)) * d.NT : 0;
   d.nG = (p.roles & PIPE_ROLE_G) ? (2 + post) * nrb * nrb : 0;
   d.nW = (p.roles & PIPE_ROLE_W) ? (d.KT * d.NT + 15) >> 4 : 0;
-  d.nT = (p.roles & PIPE_ROLE_T) ? (p.B + 31) >> 5 : 0;
+  d.nT = (p.roles & PIPE_ROLE_T) ? (p.B + 7) >> 3 : 0;
   d.nF = (p.roles & PIPE_ROLE_F) ? 1 : 0;
   d.nC = (p.roles & PIPE_ROLE_C) ? (int)((pipe_copy_elems(p) + 4095) / 4096) : 0;
   return d;
@@ -302,12 +312,14 @@ __device__ __forceinline__ void pipe_role_w(const DtfPipeArgs& p, int idx) {
 // role T: counters, log header, gather of the batch of step s+3, row indices of step s+4
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pipe_role_t(const DtfPipeArgs& p, int tb) {
+  // 8 rows per workgroup, 128 lanes per row: a workgroup moves 25 KB in and 25 KB out.  (With 32 rows per workgroup
+  // the four gather workgroups were the last of the launch to finish: 100 KB in and out through one CU's 64 B/clk.)
   const DtfTailArgs& t = p.tail;
   const int tid = threadIdx.x;
   const int a = p.q & 1;
   const int B = p.B, C = p.C;
-  const int sub = tid >> 5, l = tid & 31;
-  const int i = 32 * tb + sub;
+  const int sub = tid >> 7, l = tid & 127;
+  const int i = 8 * tb + sub;
   const int q3 = (p.q + 3) & (PIPE_SLOTS - 1), q4 = (p.q + 4) & (PIPE_SLOTS - 1);
   PIPE_STAMP_CYCLES(2);
   // both chains start here: (row index of step s+3 -> its data) and (counters -> permutation entry of step s+4)
@@ -327,16 +339,16 @@ __device__ __forceinline__ void pipe_role_t(const DtfPipeArgs& p, int tb) {
   float* drow = p.Xa + ((size_t)q3 * PIPE_ROWS + i) * p.ldxa;
   f32x4* dst = reinterpret_cast<f32x4*>(drow);
   const int n4 = p.In >> 2;
-  for (int base = 0; base < n4; base += 32 * 8) {
-    f32x4 v[8];
+  for (int base = 0; base < n4; base += 128 * 4) {
+    f32x4 v[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = base + 32 * u + l;
+    for (int u = 0; u < 4; ++u) {
+      const int k = base + 128 * u + l;
       v[u] = src[k < n4 ? k : 0];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = base + 32 * u + l;
+    for (int u = 0; u < 4; ++u) {
+      const int k = base + 128 * u + l;
       if (k < n4) dst[k] = v[u];
     }
   }
@@ -392,7 +404,8 @@ __device__ __forceinline__ void pipe_role_f(const DtfPipeArgs& p) {
     PipeW2Loads<NRB> ld;
     pipe_w2_request<NRB>(ld, rw2, rp2, (unsigned)e * 4u, blk4);
     const float w = pipe_w2_value<NRB>(ld, p.lr);
-    const int k = e >> 4, c = e & 15;
+    const int ln = (e >> 2) & 63;
+    const int k = (e >> 8) * 16 + (ln >> 4) * 4 + (e & 3), c = ln & 15;      // inverse of pipe_w2_off
     if (c < p.C) {
       if (k < p.Hd) p.W2[(size_t)k * p.C + c] = w;
       else if (k == p.Hd) p.b2[c] = w;
@@ -447,8 +460,8 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
   float (*hs)[16][17] = reinterpret_cast<float (*)[16][17]>(smem + 2176);             // [8][16][17]  h' tiles
   float (*zp)[16][16] = reinterpret_cast<float (*)[16][16]>(smem + 2176 + 2176);      // [8][16][16]  partial logits
   float (*dzs)[17] = reinterpret_cast<float (*)[17]>(smem + 2176 + 2176 + 2048);      // [16][17]     dz2 of the 16 rows
-  float* part_loss = smem + 2176 + 2176 + 2048 + 272;                                 // [4]
-  int* part_cnt = reinterpret_cast<int*>(part_loss + 4);                              // [4]
+  float* row_loss = smem + 2176 + 2176 + 2048 + 272;                                  // [16] loss of each row
+  int* row_hit = reinterpret_cast<int*>(row_loss + 16);                               // [16] prediction of each row correct
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -489,15 +502,16 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
   const float lab = bld(rlab, tid < 256 ? (unsigned)(fr * PIPE_ROWS + m0 + srow) * 4u : kOOB);
   const int lab_class = bldi(rli, tid < 256 ? (unsigned)(m0 + srow) * 4u : kOOB);
   const int ls = bldi(rctr, (unsigned)(2 * a + 1) * 4u);
-  // (3) the wave's 16 rows of the output layer of this step, in the B-operand layout of the logits product:
-  //     lane (class fr, g) holds rows n0 + 4j + g, j = 0..3
+  // (3) the wave's 16 rows of the output layer of this step: lane (class fr, g) gets rows n0 + 4g + j, j = 0..3, of
+  //     W2'(s-1) and of every row block's h'^T dz2 in one 16-byte load each
   const unsigned blk4 = (unsigned)p.HP * 64u;
   const rsrc_t rw2 = make_rsrc(p.W2m + (size_t)pg * p.HP * 16, blk4);
   const rsrc_t rp2 = make_rsrc(p.P2 + (size_t)pg * 8 * p.HP * 16, 8u * blk4);
-  PipeW2Loads<NRB> w2l[4];
+  const unsigned w2off = t_wave ? (unsigned)(tile * 64 + lane) * 16u : kOOB;
+  float w2o[4], w2p[NRB][4];
+  bld4(rw2, w2off, w2o);
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    pipe_w2_request<NRB>(w2l[j], rw2, rp2, t_wave ? (unsigned)((n0 + 4 * j + g) * 16 + fr) * 4u : kOOB, blk4);
+  for (int k = 0; k < NRB; ++k) pipe_bld4_s(rp2, w2off, (unsigned)k * blk4, w2p[k]);
   // nothing moves across this line: the scheduler otherwise sinks the operand loads next to their MFMAs and the
   // wave pays one cold round trip per 16-row block instead of one in all
   __builtin_amdgcn_sched_barrier(0);
@@ -517,13 +531,15 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
     // the output layer brought up to date while the matrix pipe works
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      w2v[j] = pipe_w2_value<NRB>(w2l[j], p.lr);
-      w2t[tile][4 * j + g][fr] = w2v[j];
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NRB; ++k) sum += w2p[k][j];
+      w2v[j] = w2o[j] - p.lr * sum;                    // row n0 + 4g + j, class fr
+      w2t[tile][4 * g + j][fr] = w2v[j];
     }
     if (rbl == 0) {                                    // one workgroup keeps W2'(s) for the next launch
-      float* out = p.W2m + (size_t)a * p.HP * 16;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) out[(n0 + 4 * j + g) * 16 + fr] = w2v[j];
+      const f32x4 w4 = {w2v[0], w2v[1], w2v[2], w2v[3]};
+      *reinterpret_cast<f32x4*>(p.W2m + (size_t)a * p.HP * 16 + (size_t)(tile * 64 + lane) * 4) = w4;
     }
     PIPE_STAMP(2);
     float zv[4];
@@ -538,15 +554,25 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
     //      operations of one wave execute in order, no workgroup barrier needed) ----
     __builtin_amdgcn_wave_barrier();
     f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-    z0 = MFMA16(hs[tile][fr][g], w2v[0], z0);
-    z1 = MFMA16(hs[tile][fr][4 + g], w2v[1], z1);
-    z0 = MFMA16(hs[tile][fr][8 + g], w2v[2], z0);
-    z1 = MFMA16(hs[tile][fr][12 + g], w2v[3], z1);
+    // (MFMA step j takes hidden column n0 + 4g + j: the order in which the output-layer rows sit in the lane)
+    z0 = MFMA16(hs[tile][fr][4 * g], w2v[0], z0);
+    z1 = MFMA16(hs[tile][fr][4 * g + 1], w2v[1], z1);
+    z0 = MFMA16(hs[tile][fr][4 * g + 2], w2v[2], z0);
+    z1 = MFMA16(hs[tile][fr][4 * g + 3], w2v[3], z1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) zp[tile][4 * g + r][fr] = z0[r] + z1[r];
     if (!post) {                                       // z1 of this batch: the next launch's accuracy-only rows start from it
       const f32x4 z4 = {zv[0], zv[1], zv[2], zv[3]};
       *reinterpret_cast<f32x4*>(p.Z1 + (size_t)a * PIPE_MAT + pipe_frag(rb, tile, lane)) = z4;
+    }
+  }
+  // operands of stages 4 and 5 that do not depend on the softmax are fetched from LDS while the wave would wait
+  float w2b[4] = {0.f, 0.f, 0.f, 0.f}, ha[4] = {0.f, 0.f, 0.f, 0.f};
+  if (t_wave && !post) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w2b[j] = w2t[tile][fr][4 * j + g];
+      ha[j] = hs[tile][4 * j + g][fr];
     }
   }
   __syncthreads();
@@ -565,37 +591,30 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
     int hit = 0;
     pipe_row_head(z, lab, lab_class, fr < p.C, row_ok && !post, fr, p.loss_mode, p.inv_b, loss, hit, dz);
     dzs[srow][fr] = dz;
-    float loss_acc = (fr == 0 && row_ok) ? loss : 0.f;
-    int cnt = (fr == 0 && row_ok) ? hit : 0;
-    loss_acc += __shfl_xor(loss_acc, 16);
-    loss_acc += __shfl_xor(loss_acc, 32);
-    cnt += __shfl_xor(cnt, 16);
-    cnt += __shfl_xor(cnt, 32);
-    if (lane == 0) {
-      part_loss[wave] = loss_acc;
-      part_cnt[wave] = cnt;
+    if (fr == 0) {                                     // per-row results; added up after the barrier, off the dependent path
+      row_loss[srow] = row_ok ? loss : 0.f;
+      row_hit[srow] = row_ok ? hit : 0;
     }
   }
   __syncthreads();
   PIPE_STAMP(6);
-  if (tid == 0) {
-    int* rec = p.wlog + (size_t)DTF_WLOG_INTS * (ls % p.log_cap);
-    const int c = (part_cnt[0] + part_cnt[1]) + (part_cnt[2] + part_cnt[3]);
-    if (post) {
-      rec[36 + rb] = c;
-    } else {
-      rec[4 + rb] = __float_as_int((part_loss[0] + part_loss[1]) + (part_loss[2] + part_loss[3]));
-      rec[20 + rb] = c;
+  if (post) {
+    if (tid == 0) {
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c += row_hit[r];
+      p.wlog[(size_t)DTF_WLOG_INTS * (ls % p.log_cap) + 36 + rb] = c;
     }
+    return;
   }
-  if (post || !t_wave) return;
+  if (!t_wave) return;
   // ---- stage 4: dz1 tile = (dz2 W2^T) masked by the ReLU, kept for the next launch ----
   {
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-    d0 = MFMA16(dzs[fr][g], w2t[tile][fr][g], d0);
-    d1 = MFMA16(dzs[fr][4 + g], w2t[tile][fr][4 + g], d1);
-    d0 = MFMA16(dzs[fr][8 + g], w2t[tile][fr][8 + g], d0);
-    d1 = MFMA16(dzs[fr][12 + g], w2t[tile][fr][12 + g], d1);
+    d0 = MFMA16(dzs[fr][g], w2b[0], d0);
+    d1 = MFMA16(dzs[fr][4 + g], w2b[1], d1);
+    d0 = MFMA16(dzs[fr][8 + g], w2b[2], d0);
+    d1 = MFMA16(dzs[fr][12 + g], w2b[3], d1);
     f32x4 d4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) d4[r] = (col < p.Hd && hreg[r] > 0.f) ? d0[r] + d1[r] : 0.f;
@@ -605,13 +624,25 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
   // ---- stage 5: this row block's share of the output layer's gradient, h'^T dz2 ----
   {
     f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
-    u0 = MFMA16(hs[tile][g][fr], dzs[g][fr], u0);
-    u1 = MFMA16(hs[tile][4 + g][fr], dzs[4 + g][fr], u1);
-    u0 = MFMA16(hs[tile][8 + g][fr], dzs[8 + g][fr], u0);
-    u1 = MFMA16(hs[tile][12 + g][fr], dzs[12 + g][fr], u1);
-    float* out = p.P2 + (((size_t)a * 8 + rb) * p.HP + n0) * 16;
+    u0 = MFMA16(ha[0], dzs[g][fr], u0);
+    u1 = MFMA16(ha[1], dzs[4 + g][fr], u1);
+    u0 = MFMA16(ha[2], dzs[8 + g][fr], u0);
+    u1 = MFMA16(ha[3], dzs[12 + g][fr], u1);
+    // result (hidden n0 + 4g + r, class fr): the lane's four values are one entry of the output-layer layout
+    const f32x4 u4 = {u0[0] + u1[0], u0[1] + u1[1], u0[2] + u1[2], u0[3] + u1[3]};
+    *reinterpret_cast<f32x4*>(p.P2 + ((size_t)a * 8 + rb) * p.HP * 16 + (size_t)(tile * 64 + lane) * 4) = u4;
+  }
+  if (tid == 0) {                                      // the row block's log entries, in row order
+    float l = 0.f;
+    int c = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[(4 * g + r) * 16 + fr] = u0[r] + u1[r];
+    for (int r = 0; r < 16; ++r) {
+      l += row_loss[r];
+      c += row_hit[r];
+    }
+    int* rec = p.wlog + (size_t)DTF_WLOG_INTS * (ls % p.log_cap);
+    rec[4 + rb] = __float_as_int(l);
+    rec[20 + rb] = c;
   }
   PIPE_STAMP(7);
 }
@@ -639,7 +670,8 @@ __device__ __forceinline__ void pipe_role_c(const DtfPipeArgs& p, int cb) {
     e -= 2 * nWm;
     if (e < 2 * nW2) {
       const int w = e >= nW2 ? e - nW2 : e;
-      const int k = w >> 4, c = w & 15;
+      const int ln = (w >> 2) & 63;
+      const int k = (w >> 8) * 16 + (ln >> 4) * 4 + (w & 3), c = ln & 15;    // inverse of pipe_w2_off
       float v = 0.f;
       if (c < p.C) {
         if (k < p.Hd) v = p.W2[(size_t)k * p.C + c];
