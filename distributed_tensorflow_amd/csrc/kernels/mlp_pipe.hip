@@ -467,7 +467,8 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NT = p.HP >> 4;
-  if (wave >= (NT > 4 ? NT : 4)) return;              // (waves 0..3 also carry the softmax rows)
+  const int bk_wave = NT > 4 ? NT : 4;                // first wave without a tile or softmax rows: the bookkeeper
+  if (wave > bk_wave) return;                         // (waves 0..3 also carry the softmax rows)
   const int fr = lane & 15, g = lane >> 4;
   const bool post = rbl >= NRB;                       // workgroup-uniform
   const int rb = post ? rbl - NRB : rbl;
@@ -598,16 +599,27 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
   }
   __syncthreads();
   PIPE_STAMP(6);
-  if (post) {
-    if (tid == 0) {
+  if (wave == bk_wave) {
+    // the row block's log entries, added up in row order by a wave that has nothing else to do
+    if (lane == 0) {
+      float l = 0.f;
       int c = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) c += row_hit[r];
-      p.wlog[(size_t)DTF_WLOG_INTS * (ls % p.log_cap) + 36 + rb] = c;
+      for (int r = 0; r < 16; ++r) {
+        l += row_loss[r];
+        c += row_hit[r];
+      }
+      int* rec = p.wlog + (size_t)DTF_WLOG_INTS * (ls % p.log_cap);
+      if (post) {
+        rec[36 + rb] = c;
+      } else {
+        rec[4 + rb] = __float_as_int(l);
+        rec[20 + rb] = c;
+      }
     }
     return;
   }
-  if (!t_wave) return;
+  if (post || !t_wave) return;
   // ---- stage 4: dz1 tile = (dz2 W2^T) masked by the ReLU, kept for the next launch ----
   {
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
@@ -631,18 +643,6 @@ __device__ __forceinline__ void pipe_role_l(const DtfPipeArgs& p, int rbl, float
     // result (hidden n0 + 4g + r, class fr): the lane's four values are one entry of the output-layer layout
     const f32x4 u4 = {u0[0] + u1[0], u0[1] + u1[1], u0[2] + u1[2], u0[3] + u1[3]};
     *reinterpret_cast<f32x4*>(p.P2 + ((size_t)a * 8 + rb) * p.HP * 16 + (size_t)(tile * 64 + lane) * 4) = u4;
-  }
-  if (tid == 0) {                                      // the row block's log entries, in row order
-    float l = 0.f;
-    int c = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      l += row_loss[r];
-      c += row_hit[r];
-    }
-    int* rec = p.wlog + (size_t)DTF_WLOG_INTS * (ls % p.log_cap);
-    rec[4 + rb] = __float_as_int(l);
-    rec[20 + rb] = c;
   }
   PIPE_STAMP(7);
 }
