@@ -257,14 +257,14 @@ struct DtfPipeArgs {
   float* Xa;                // [8][128][ldxa] gathered batch rows, column In = 1 (rows >= B and columns > In stay zero)
   float* labg;              // [8][16][128] gathered label rows, class-major, zero padded
   int* ridx;                // [8][ridx_len] dataset row of each logical row ([0,B) batch, [B,2B) the batch before it); host use
-  float* Wm;                // [2][KAp][HP] W1 with b1 as row In, zero padded
-  float* W2m;               // [2][HP][16] W2 with b2 as row Hd, zero padded
+  float* Wm;                // [2][KAp * HP] W1 with b1 as row In, zero padded, in MFMA-fragment order per 16x16 tile
+  float* W2m;               // [2][HP * 16] W2 with b2 as row Hd, zero padded, fragment order per 16 rows
   float* Q;                 // [2][16384] X'(s) W1'(s-2) - lr G(s,s-2) dz1(s-2), MFMA result layout per 16x16 tile
   float* Z1;                // [2][16384] z1 of a step before the ReLU (what the next step's accuracy-only rows start from), same layout
   int* labi;                // [8][128] class of each gathered row (argmax of its label row)
   float* GG;                // [2][3][16384] Gram matrices of column batch c: X'(c) X'(c)^T, X'(c+1) X'(c)^T, X'(c+2) X'(c)^T, A-operand layout
   float* D1;                // [2][16384] dz1 of a step (rows >= B zero), B-operand layout
-  float* P2;                // [2][8][HP][16] per row block: h'^T dz2
+  float* P2;                // [2][8][HP * 16] per row block: h'^T dz2, same order as W2m
   int* ctr;                 // [2][2] {global_step, local_step} a step reads (the tail writes the other generation)
   float* W1; float* b1; float* W2; float* b2;         // flat parameters: read by the prime launch, written by the flush launch
   int* wlog;                // [log_cap][DTF_WLOG_INTS]

@@ -94,9 +94,12 @@ __device__ __forceinline__ void pipe_bld4_s(rsrc_t r, unsigned voff, unsigned so
 //                                                        lane = ((k % 16) / 4) * 16 + c, e = k % 4
 //     = the MFMA result layout of h'^T dz2 (what a row workgroup produces) and, with MFMA step j taking k = 4g + j,
 //       the B-operand layout of the logits product (what the next launch's row workgroups consume): 16-byte loads
+//   working copy of W1' (Wm: k = input index, n = hidden column): B operand of the Q products and MFMA result of the
+//     weight update alike, tile (k / 16, n / 16) of KT x NT tiles, lane = ((k % 16) / 4) * 16 + n % 16, e = k % 4
 #define PIPE_MAT 16384                    // floats per operand-layout matrix (8 x 8 tiles x 256)
 __host__ __device__ __forceinline__ int pipe_w2_off(int k, int c) { return ((k >> 4) * 64 + ((k & 15) >> 2) * 16 + c) * 4 + (k & 3); }
 __host__ __device__ __forceinline__ unsigned pipe_frag(int t0, int t1, int lane) { return (unsigned)(((t0 * 8 + t1) * 64 + lane) * 4); }
+__host__ __device__ __forceinline__ unsigned pipe_wfrag(int kt, int nt, int NT, int lane) { return (unsigned)(((kt * NT + nt) * 64 + lane) * 4); }
 
 struct PipeDims {
   int NT, KT, nL, nQ, nG, nW, nT, nF, nC;
@@ -149,8 +152,6 @@ __device__ __forceinline__ void pipe_role_q(const DtfPipeArgs& p, int idx, float
   const rsrc_t rg = make_rsrc(p.GG + ((size_t)pg * 3 + 2) * PIPE_MAT, PIPE_MAT * 4u);
   const rsrc_t rd = make_rsrc(p.D1 + (size_t)pg * PIPE_MAT, PIPE_MAT * 4u);
   const int nX = p.KAp >> 4;
-  const unsigned hp4 = (unsigned)p.HP * 4u;
-  const unsigned bcol = (unsigned)(n0 + fr) * 4u;
   float av[4][4], bv[4][4];
   float scale[4];
 #pragma unroll
@@ -173,8 +174,7 @@ __device__ __forceinline__ void pipe_role_q(const DtfPipeArgs& p, int idx, float
           bv[i][j] = v;
         }
       } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bv[i][j] = bld(rw, (k + j) * hp4 + bcol);
+        bld4(rw, pipe_wfrag(c, nt, NT, lane) * 4u, bv[i]);
       }
     } else if (c - nX < NRB && !p.prime) {       // (prime: no pending gradient)
       scale[i] = -p.lr;
@@ -205,6 +205,7 @@ __device__ __forceinline__ void pipe_role_q(const DtfPipeArgs& p, int idx, float
     float* out = post ? p.Z1 + (size_t)a * PIPE_MAT : p.Q + (size_t)pg * PIPE_MAT;
     out[pipe_frag(rb, nt, (e_rl >> 2) * 16 + e_cl) + (e_rl & 3)] = s;
   }
+  PIPE_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -244,13 +245,16 @@ __device__ __forceinline__ void pipe_role_g(const DtfPipeArgs& p, int idx, float
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
+  PIPE_STAMP(1);
   __syncthreads();
+  PIPE_STAMP(2);
   if (threadIdx.x < 256) {
     const int e_r = (threadIdx.x >> 6) & 3, e_ln = threadIdx.x & 63;
     const int e_rl = 4 * (e_ln >> 4) + e_r, e_cl = e_ln & 15;
     const float s = pipe_reduce16(red, e_r, e_ln);
     p.GG[((size_t)a * 3 + kind) * PIPE_MAT + pipe_frag(rbi, cbj, (e_cl >> 2) * 16 + e_rl) + (e_cl & 3)] = s;
   }
+  PIPE_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -272,7 +276,7 @@ __device__ __forceinline__ void pipe_role_w(const DtfPipeArgs& p, int idx) {
   const rsrc_t rx = make_rsrc(p.Xa + (size_t)slot * PIPE_ROWS * p.ldxa, slot_bytes);
   const rsrc_t rd = make_rsrc(p.D1 + (size_t)pg * PIPE_MAT, PIPE_MAT * 4u);
   const rsrc_t rw = make_rsrc(p.Wm + (size_t)pg * p.KAp * p.HP, (unsigned)p.KAp * (unsigned)p.HP * 4u);
-  const unsigned ldx4 = (unsigned)p.ldxa * 4u, hp4 = (unsigned)p.HP * 4u;
+  const unsigned ldx4 = (unsigned)p.ldxa * 4u;
   const unsigned a_base = (unsigned)(4 * g) * ldx4 + (unsigned)(m0 + fr) * 4u;
   float av[NRB][4], bv[NRB][4], wold[4];
 #pragma unroll
@@ -281,8 +285,7 @@ __device__ __forceinline__ void pipe_role_w(const DtfPipeArgs& p, int idx) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) av[rb][j] = pipe_bld_s(rx, a_base, (unsigned)(16 * rb + j) * ldx4);
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) wold[r] = bld(rw, (unsigned)(m0 + 4 * g + r) * hp4 + (unsigned)(n0 + fr) * 4u);
+  bld4(rw, pipe_wfrag(mt, nt, NT, lane) * 4u, wold);     // rows m0 + 4g + r, column n0 + fr: one fragment entry
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb) {
@@ -293,18 +296,20 @@ __device__ __forceinline__ void pipe_role_w(const DtfPipeArgs& p, int idx) {
   }
   const int col = n0 + fr;
   PIPE_STAMP(1);
+  f32x4 w4;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = m0 + 4 * g + r;
-    const float w = wold[r] - p.lr * (acc0[r] + acc1[r]);
-    if (p.flush) {
+  for (int r = 0; r < 4; ++r) w4[r] = wold[r] - p.lr * (acc0[r] + acc1[r]);
+  if (p.flush) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 4 * g + r;
       if (col < p.Hd) {
-        if (row < p.In) p.W1[(size_t)row * p.Hd + col] = w;
-        else if (row == p.In) p.b1[col] = w;
+        if (row < p.In) p.W1[(size_t)row * p.Hd + col] = w4[r];
+        else if (row == p.In) p.b1[col] = w4[r];
       }
-    } else {
-      p.Wm[((size_t)a * p.KAp + row) * p.HP + col] = w;
     }
+  } else {
+    *reinterpret_cast<f32x4*>(p.Wm + (size_t)a * p.KAp * p.HP + pipe_wfrag(mt, nt, NT, lane)) = w4;
   }
 }
 
@@ -658,7 +663,10 @@ __device__ __forceinline__ void pipe_role_c(const DtfPipeArgs& p, int cb) {
     if (e >= total) break;
     if (e < 2 * nWm) {
       const int w = e >= nWm ? e - nWm : e;
-      const int k = w / p.HP, c = w - k * p.HP;
+      // inverse of pipe_wfrag: w = ((kt * NT + nt) * 64 + lane) * 4 + (k % 4)
+      const int NTc = p.HP >> 4;
+      const int tl = w >> 8, ln = (w >> 2) & 63;
+      const int k = (tl / NTc) * 16 + (ln >> 4) * 4 + (w & 3), c = (tl % NTc) * 16 + (ln & 15);
       float v = 0.f;
       if (c < p.Hd) {
         if (k < p.In) v = p.W1[(size_t)k * p.Hd + c];
