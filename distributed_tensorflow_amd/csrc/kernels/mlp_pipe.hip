@@ -114,7 +114,8 @@ __host__ __device__ __forceinline__ PipeDims pipe_dims(const DtfPipeArgs& p, int
   d.KT = p.KAp >> 4;
   d.nL = (p.roles & PIPE_ROLE_L) ? nrb * (1 + post) : 0;
   d.nQ = (p.roles & PIPE_ROLE_Q) ? nrb * (1 + (p.prime ? post : 0)) * d.NT : 0;
-  d.nG = (p.roles & PIPE_ROLE_G) ? (2 + post) * nrb * nrb : 0;
+  // G(s,s) is symmetric: only its tiles on and above the diagonal are computed (and stored in both orientations)
+  d.nG = (p.roles & PIPE_ROLE_G) ? 2 * nrb * nrb + post * (nrb * (nrb + 1) / 2) : 0;
   d.nW = (p.roles & PIPE_ROLE_W) ? (d.KT * d.NT + 15) >> 4 : 0;
   d.nT = (p.roles & PIPE_ROLE_T) ? (p.B + 7) >> 3 : 0;
   d.nF = (p.roles & PIPE_ROLE_F) ? 1 : 0;
@@ -217,10 +218,23 @@ __device__ __forceinline__ void pipe_role_g(const DtfPipeArgs& p, int idx, float
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, g = lane >> 4;
-  int kind = idx / (NRB * NRB);
-  const int rem = idx - kind * NRB * NRB;
-  if (p.R <= p.B) kind += 1;                           // without accuracy-only rows G(s,s) is not needed
-  const int rbi = rem / NRB, cbj = rem - rbi * NRB;
+  // kinds 1 and 2 first (NRB x NRB tiles each), then - with accuracy-only rows - the upper triangle of kind 0
+  int kind, rbi, cbj;
+  if (idx < 2 * NRB * NRB) {
+    kind = 1 + idx / (NRB * NRB);
+    const int rem = idx - (kind - 1) * NRB * NRB;
+    rbi = rem / NRB;
+    cbj = rem - rbi * NRB;
+  } else {
+    kind = 0;
+    int t = idx - 2 * NRB * NRB;
+    rbi = 0;
+    while (t >= NRB - rbi) {
+      t -= NRB - rbi;
+      ++rbi;
+    }
+    cbj = rbi + t;
+  }
   const int m0 = rbi * 16, n0 = cbj * 16;
   const int a = p.q & 1;
   const unsigned slot_bytes = (unsigned)PIPE_ROWS * (unsigned)p.ldxa * 4u;
@@ -252,7 +266,9 @@ __device__ __forceinline__ void pipe_role_g(const DtfPipeArgs& p, int idx, float
     const int e_r = (threadIdx.x >> 6) & 3, e_ln = threadIdx.x & 63;
     const int e_rl = 4 * (e_ln >> 4) + e_r, e_cl = e_ln & 15;
     const float s = pipe_reduce16(red, e_r, e_ln);
-    p.GG[((size_t)a * 3 + kind) * PIPE_MAT + pipe_frag(rbi, cbj, (e_cl >> 2) * 16 + e_rl) + (e_cl & 3)] = s;
+    float* out = p.GG + ((size_t)a * 3 + kind) * PIPE_MAT;
+    out[pipe_frag(rbi, cbj, (e_cl >> 2) * 16 + e_rl) + (e_cl & 3)] = s;
+    if (kind == 0 && cbj != rbi) out[pipe_frag(cbj, rbi, (e_rl >> 2) * 16 + e_cl) + (e_rl & 3)] = s;    // the mirrored tile
   }
   PIPE_STAMP(6);
 }

@@ -29,8 +29,8 @@ stamps = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
 t_ab = torch.zeros(4, dtype=torch.int64, device=dev)
 lib.dtf_set_stamp_buffer_pipe(stamps.data_ptr())
 s = torch.cuda.current_stream().cuda_stream
-# grid order: L (14), T (13), W (22), Q (49), G (147)
-ranges = [("L", 0, 14), ("T", 14, 27), ("W", 27, 49), ("Q", 49, 98), ("G", 98, 245)]
+# grid order: L (14), T (13), W (22), Q (49), G (126)
+ranges = [("L", 0, 14), ("T", 14, 27), ("W", 27, 49), ("Q", 49, 98), ("G", 98, 224)]
 
 
 def show(tag, rel, lo, hi):
