@@ -46,11 +46,12 @@ class StepRecord:
 
 
 class _no_gc:
-    """Collect garbage now, then keep the cyclic collector off for the duration of the block (a stream capture)."""
+    """Keep the cyclic garbage collector off for the duration of the block (a stream capture).  Garbage that exists
+    already stays where it is until the collector runs again after the block; nothing is collected first (a full
+    collection costs 30 ms in a process that has imported torch)."""
 
     def __enter__(self):
         import gc
-        gc.collect()
         self._was = gc.isenabled()
         gc.disable()
 
@@ -292,12 +293,20 @@ class MLPProgram:
         self._started = True
 
     def _rows_of_step(self, step: int) -> torch.Tensor:
-        """Dataset rows of the batch of 0-based local step ``step`` (its epoch's permutation must be resident)."""
-        pos = torch.arange(step * self.B, (step + 1) * self.B, dtype=torch.int64, device=self.device)
+        """Dataset rows of the batch of 0-based local step ``step``, computed on the host (the same permutation the
+        device holds) and uploaded: no device arithmetic, whose first use costs tens of milliseconds."""
+        import numpy as np
+        from ..data.mnist import epoch_permutation
+        pos = np.arange(step * self.B, (step + 1) * self.B, dtype=np.int64)
         epoch, off = pos // self.data.n, pos % self.data.n
         if self.data.perm is None:
-            return off
-        return self.data.perm[(epoch & 1), off].long()
+            rows = off
+        else:
+            rows = np.empty(self.B, dtype=np.int64)
+            for e in np.unique(epoch):
+                m = epoch == e
+                rows[m] = epoch_permutation(self.data.seed, int(e), self.data.n)[off[m]]
+        return torch.from_numpy(rows).to(self.device)
 
     def _start_pipe(self, q: int) -> None:
         """The pipelined step finds the batches of its first three steps gathered (a step gathers the batch three
@@ -553,26 +562,33 @@ class MLPProgram:
         """Records of local steps ``[first, first+count)`` (0-based).  Synchronises with the device."""
         if count > self.log_cap:
             raise ValueError("asked for more records than the log ring holds")
-        log = self._log_host()
-        out = []
-        for s in range(first_local_step, first_local_step + count):
-            rec = log[s % self.log_cap]
-            loss = struct.unpack("<f", struct.pack("<i", int(rec[0])))[0]
-            out.append(StepRecord(local_step=s + 1, global_step=int(rec[3]), loss=loss, train_correct=int(rec[1]),
-                                  batch=self.B))
+        log = self._log_host(first_local_step, count).numpy()
+        loss = log[:, 0].copy().view("<f4").tolist()
+        correct, post, gs = log[:, 1].tolist(), log[:, 2].tolist(), log[:, 3].tolist()
+        out = [StepRecord(local_step=first_local_step + i + 1, global_step=gs[i], loss=loss[i], train_correct=correct[i],
+                          batch=self.B) for i in range(count)]
         if self.post:
             # the post-update count of step s is produced by the accuracy-only rows of step s+1
-            for i, r in enumerate(out[:-1]):
-                nxt = log[(first_local_step + i + 1) % self.log_cap]
-                r.post_correct = int(nxt[2])
+            for i in range(count - 1):
+                out[i].post_correct = post[i + 1]
         return out
 
-    def _log_host(self) -> torch.Tensor:
-        """The log ring on the host as ``[capacity, 4]`` int32 records {loss bits, correct, post, global_step}.
-        The two-launch step logs per-row-block partial sums; they are folded here in a fixed order."""
+    def _log_host(self, first_local_step: int = 0, count: Optional[int] = None) -> torch.Tensor:
+        """Records of local steps ``[first, first + count)`` (default: the whole ring, indexed by step % capacity) on
+        the host as ``[count, 4]`` int32 {loss bits, correct, post, global_step}.  The two-launch and the one-launch
+        step log per-row-block partial sums; they are folded here in a fixed order.  Only the rows asked for cross
+        the host link."""
+        src = self.wlog if (self.fused2 or self.pipe) else self.log
+        if count is None:
+            w = src.cpu()
+        else:
+            lo = first_local_step % self.log_cap
+            if lo + count <= self.log_cap:
+                w = src[lo:lo + count].cpu()
+            else:                                       # the range wraps around the ring
+                w = torch.cat([src[lo:], src[:lo + count - self.log_cap]]).cpu()
         if not (self.fused2 or self.pipe):
-            return self.log.cpu()
-        w = self.wlog.cpu()
+            return w
         nb = (self.R + 15) // 16
         loss = torch.zeros(w.shape[0], dtype=torch.float32)
         parts = w[:, 4:4 + nb].contiguous().view(torch.float32)
@@ -589,7 +605,7 @@ class MLPProgram:
     def post_count_logged_at(self, local_step: int) -> int:
         """Correct predictions on the accuracy-only rows of 0-based step ``local_step`` (= the batch of the
         step before it, scored with the parameters that step produced)."""
-        return int(self._log_host()[local_step % self.log_cap][2])
+        return int(self._log_host(local_step, 1)[0][2])
 
     def post_correct_of_last_step(self) -> int:
         """Post-update accuracy count of the most recent step (needs one extra forward)."""
