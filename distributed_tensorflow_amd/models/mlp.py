@@ -150,6 +150,8 @@ class MLPProgram:
         self._eval_buf: Dict = {}
         self._args = [self._build_args(q) for q in range(self.P)] if self.is_cuda else None
         self._started = False
+        self.pipe_primes = 0                    # prime launches so far (diagnostic)
+        self._pipe_live = None                  # _pipe_token() of the state the pipeline's working copies continue from
         # Called at the end of every step, inside the captured region: the engine's gradient
         # aggregation + shard update + parameter redistribution when the update is not fused.
         self.after_compute = None
@@ -337,13 +339,30 @@ class MLPProgram:
         b.labg[before].copy_(b.labg[q])
         b.labi[before].copy_(b.labi[q])
 
-    def _pipe_open(self) -> None:
-        """Prime launch of a run of pipelined steps: working copies and Q of the next step from the flat parameters."""
-        ops.pipe_prime(self._args[self.steps_enqueued % self.P]["pipe_prime"])
+    def _pipe_token(self):
+        """What the pipeline's working copies were built from: a change of any of these between two runs (parameters
+        or counters rewritten through the state's methods or by an in-place tensor operation, steps enqueued
+        elsewhere) means the next run starts with a prime launch.  Kernels write through raw pointers and leave the
+        tensors' version counters alone."""
+        st = self.state
+        return (st.values_version, st.params._version, st.state._version, self.steps_enqueued)
 
-    def _pipe_close(self) -> None:
-        """Flush launch: the parameters after the last enqueued step into the flat buffer."""
-        ops.pipe_flush(self._args[(self.steps_enqueued - 1) % self.P]["pipe_flush"])
+    def _pipe_open(self) -> None:
+        """Start of a run of pipelined steps.  The flush launch at the end of a run only materialises the flat
+        parameters: working copies, pending gradients and the products for the next step stay as the last step left
+        them, so a run that follows with nothing rewritten in between continues the pipeline as if it were one longer
+        run.  Otherwise the prime launch: working copies and Q of the next step from the flat parameters."""
+        if self._pipe_live == self._pipe_token():
+            return
+        ops.pipe_prime(self._args[self.steps_enqueued % self.P]["pipe_prime"])
+        self.pipe_primes += 1
+
+    def _pipe_close(self, launched: bool = False) -> None:
+        """Flush launch: the parameters after the last enqueued step into the flat buffer (``launched``: the last
+        graph of the run ended with it)."""
+        if not launched:
+            ops.pipe_flush(self._args[(self.steps_enqueued - 1) % self.P]["pipe_flush"])
+        self._pipe_live = self._pipe_token()
 
     def _pipe_step(self) -> None:
         ops.pipe_step(self._args[self.steps_enqueued % self.P]["pipe_step"])
@@ -441,11 +460,14 @@ class MLPProgram:
         dst[:self.B] = rows
 
     # ------------------------------------------------------------------ multi-step execution
-    def _graph_key(self, n: int, at: int):
-        return (n, at % self.P) if self.phase_period == 1 else (n, at % self.P, at % self.phase_period)
+    def _graph_key(self, n: int, at: int, last: bool = False):
+        key = (n, at % self.P) if self.phase_period == 1 else (n, at % self.P, at % self.phase_period)
+        return key + ("flush",) if last and self.pipe else key
 
-    def _graph_for(self, n: int):
-        key = self._graph_key(n, self.steps_enqueued)
+    def _graph_for(self, n: int, last: bool = False):
+        """The graph of ``n`` steps from ``steps_enqueued`` on.  ``last`` (pipelined step): the graph of the last
+        launch of a run ends with the flush launch, so that a short run is ONE graph launch."""
+        key = self._graph_key(n, self.steps_enqueued, last)
         g = self._graphs.get(key)
         if g is None:
             saved = self.steps_enqueued
@@ -458,9 +480,11 @@ class MLPProgram:
             with _no_gc():
                 with torch.cuda.graph(g):
                     for _ in range(n):
-                        # (a graph of pipelined steps holds the step launches only: run() primes before its first
-                        # graph and flushes after its last, the pipeline state carries over between graphs)
+                        # (a graph of pipelined steps holds the step launches, the last graph of a run the flush
+                        # launch as well; the pipeline state carries over between graphs and between runs)
                         self._pipe_step() if self.pipe else self.enqueue_step()
+                    if last and self.pipe:
+                        ops.pipe_flush(self._args[(self.steps_enqueued - 1) % self.P]["pipe_flush"])
             self.steps_enqueued = saved   # capture enqueues nothing
             self._graphs[key] = g
         return g
@@ -477,7 +501,7 @@ class MLPProgram:
             if self.use_graphs and remaining >= 2:
                 if remaining >= graph_steps:
                     n = graph_steps
-                elif exact_tail or self._graph_key(remaining, at) in self._graphs:
+                elif exact_tail or self._graph_key(remaining, at, True) in self._graphs:
                     n = remaining
                 else:
                     n = 1 << (remaining.bit_length() - 1)
@@ -504,9 +528,10 @@ class MLPProgram:
         saved = self.steps_enqueued
         self.steps_enqueued += start_offset
         try:
-            for n in list(self._launch_sizes(n_steps, graph_steps, exact_tail=True)):
+            sizes = list(self._launch_sizes(n_steps, graph_steps, exact_tail=True))
+            for i, n in enumerate(sizes):
                 if n >= 2:
-                    self._graph_for(n)
+                    self._graph_for(n, last=i == len(sizes) - 1)
                 self.steps_enqueued += n
         finally:
             self.steps_enqueued = saved
@@ -546,17 +571,20 @@ class MLPProgram:
             return
         if self.pipe:
             self._pipe_open()
-        for n in list(self._launch_sizes(n_steps, graph_steps)):
+        sizes = list(self._launch_sizes(n_steps, graph_steps))
+        flushed = False
+        for i, n in enumerate(sizes):
             self.data.prepare(self.steps_enqueued, n + self._lookahead(), self.B)
             if n >= 2:
-                self._graph_for(n).replay()
+                flushed = self.pipe and i == len(sizes) - 1
+                self._graph_for(n, last=flushed).replay()
                 self.steps_enqueued += n
             elif self.pipe:
                 self._pipe_step()
             else:
                 self.enqueue_step()
         if self.pipe:
-            self._pipe_close()
+            self._pipe_close(launched=flushed)
 
     def read_log(self, first_local_step: int, count: int) -> List[StepRecord]:
         """Records of local steps ``[first, first+count)`` (0-based).  Synchronises with the device."""

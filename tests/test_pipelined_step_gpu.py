@@ -140,3 +140,26 @@ def test_parameters_are_materialised_between_runs():
     la, lb = prog.read_log(10, 6), prog2.read_log(10, 6)
     for x, y in zip(la, lb):
         assert abs(x.loss - y.loss) < 2e-5
+
+
+def test_runs_continue_the_pipeline():
+    """A run that follows another with nothing rewritten in between starts without a prime launch and computes bit
+    for bit what one longer run computes; the last graph of a run holds the flush launch."""
+    st, prog = _program(True)
+    for n in (7, 1, 12, 20):
+        prog.run(n, 8)
+    st2, prog2 = _program(True)
+    prog2.run(40, 8)
+    torch.cuda.synchronize()
+    assert prog.pipe_primes == 1 and prog2.pipe_primes == 1
+    for n in st.names():
+        assert torch.equal(st.var(n), st2.var(n)), n
+    ra, rb = prog.read_log(0, 40), prog2.read_log(0, 40)
+    assert [r.loss for r in ra] == [r.loss for r in rb]
+    assert any(k[-1] == "flush" for k in prog._graphs)
+    # counters rewritten by the host (a restore sets global_step): primed again, logged from the new value on
+    st.load_values({n: st.var(n).clone() for n in st.names()}, global_step=1000)
+    prog.run(3, 8)
+    torch.cuda.synchronize()
+    assert prog.pipe_primes == 2
+    assert [r.global_step for r in prog.read_log(40, 3)] == [1000, 1001, 1002]
