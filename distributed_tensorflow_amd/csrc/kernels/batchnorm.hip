@@ -211,8 +211,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const unsigned sho
 // MASK: 0 = no activation, 1 = ReLU without residual (sign of a*x + b), 2 = ReLU after a residual (y > 0; the
 // masked dy is written to dres: it is the gradient of the residual branch and the dx kernel's input).
 // Partials: sum(dym) and sum(dym * (x - mean)).
-template <int MASK>
-__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+// SUM2 (with MASK 2 only): the output went to two consumers (the next block's main branch and its skip connection) and
+// their gradients arrive separately; dy = dy + dy2 is formed here in fp32 instead of by an addition kernel of its own
+// (three tensor passes) in front of this one.
+template <int MASK, bool SUM2>
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ dy2,
+                                                                    const unsigned short* __restrict__ x,
                                                                     const unsigned short* __restrict__ y, unsigned short* __restrict__ dres,
                                                                     const float* __restrict__ save, int64_t M, int C,
                                                                     float* __restrict__ part) {
@@ -225,13 +229,14 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const unsigne
     s[j] = sx[j] = 0.f;
   }
   for (int64_t r = w.row; r < M; r += w.step * kUnroll) {
-    u32x4 qd[kUnroll], qx[kUnroll], qy[kUnroll];
+    u32x4 qd[kUnroll], qd2[kUnroll], qx[kUnroll], qy[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t rr = r + u * w.step;
       const bool ok = rr < M;
       const size_t e = (size_t)rr * C + w.c0;
-      qd[u] = ok ? ld16(dy, e) : u32x4{0u, 0u, 0u, 0u};
+      qd[u] = ok ? (MASK == 2 ? ld16_last(dy, e) : ld16(dy, e)) : u32x4{0u, 0u, 0u, 0u};   // (MASK 2: dx reads dres instead)
+      if (SUM2) qd2[u] = ok ? ld16_last(dy2, e) : u32x4{0u, 0u, 0u, 0u};
       qx[u] = ok ? ld16(x, e) : u32x4{0u, 0u, 0u, 0u};
       if (MASK == 2) qy[u] = ok ? ld16_last(y, e) : u32x4{0u, 0u, 0u, 0u};
     }
@@ -239,12 +244,14 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const unsigne
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t rr = r + u * w.step;
       if (rr >= M) continue;
-      float d[8], xv[8], yv[8];
+      float d[8], d2[8], xv[8], yv[8];
       unpack8(qd[u], d);
+      if (SUM2) unpack8(qd2[u], d2);
       unpack8(qx[u], xv);
       if (MASK == 2) unpack8(qy[u], yv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        if (SUM2) d[j] += d2[j];
         if (MASK == 1) d[j] = (xv[j] * a[j] + b[j]) > 0.f ? d[j] : 0.f;
         if (MASK == 2) d[j] = yv[j] > 0.f ? d[j] : 0.f;
         s[j] += d[j];
@@ -367,23 +374,27 @@ DTF_EXPORT int dtf_bn_fwd(const void* x, const void* res, void* y, const float* 
 
 // Backward of the above.  mask: 0 none, 1 ReLU recomputed from x, 2 ReLU read from y (then `y` and `dres` are
 // required and dres receives the masked dy = the gradient of the residual input).  coef: [3][C] scratch.
-DTF_EXPORT int dtf_bn_bwd(const void* dy, const void* x, const void* y, void* dx, void* dres, const float* save, float* dgamma,
-                          float* dbeta, float* part, float* coef, int64_t M, int C, int mask, hipStream_t s) {
+// dy2 (optional, mask 2 only): a second gradient of the same output; the layer's dy is dy + dy2.
+DTF_EXPORT int dtf_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, void* dx, void* dres, const float* save,
+                          float* dgamma, float* dbeta, float* part, float* coef, int64_t M, int C, int mask, hipStream_t s) {
   if (!dy || !x || !dx || !save || !dgamma || !dbeta || !part || !coef) return DTF_ERR_ARG;
-  if (mask < 0 || mask > 2 || (mask == 2 && (!y || !dres))) return DTF_ERR_ARG;
+  if (mask < 0 || mask > 2 || (mask == 2 && (!y || !dres)) || (dy2 && mask != 2)) return DTF_ERR_ARG;
+  if (dy2 && !dtf_aligned16(dy2)) return DTF_ERR_ALIGN;
   if (!bn_shape_ok(M, C)) return DTF_ERR_SHAPE;
   if (!dtf_aligned16(dy) || !dtf_aligned16(x) || !dtf_aligned16(dx) || (mask == 2 && (!dtf_aligned16(y) || !dtf_aligned16(dres))))
     return DTF_ERR_ALIGN;
   const dim3 grid = bn_grid(M, C);
   const int nblk = (int)grid.x;
   const auto* ds = static_cast<const unsigned short*>(dy);
+  const auto* ds2 = static_cast<const unsigned short*>(dy2);
   const auto* xs = static_cast<const unsigned short*>(x);
   const auto* ys = static_cast<const unsigned short*>(y);
   auto* dxs = static_cast<unsigned short*>(dx);
   auto* drs = static_cast<unsigned short*>(dres);
-  if (mask == 2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, grid, dim3(kBnThreads), 0, s, ds, xs, ys, drs, save, M, C, part);
-  else if (mask == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(kBnThreads), 0, s, ds, xs, ys, drs, save, M, C, part);
-  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, dim3(kBnThreads), 0, s, ds, xs, ys, drs, save, M, C, part);
+  if (mask == 2 && ds2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<2, true>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, ys, drs, save, M, C, part);
+  else if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<2, false>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, ys, drs, save, M, C, part);
+  else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, false>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, ys, drs, save, M, C, part);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<0, false>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, ys, drs, save, M, C, part);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(dtf_cdiv(C, 4)), dim3(kBnThreads), 0, s, part, nblk, M, C, save, dgamma, dbeta, coef);
   if (mask == 2) hipLaunchKernelGGL(bn_bwd_dx_kernel<0>, grid, dim3(kBnThreads), 0, s, drs, xs, dxs, save, coef, M, C);
   else if (mask == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<1>, grid, dim3(kBnThreads), 0, s, ds, xs, dxs, save, coef, M, C);

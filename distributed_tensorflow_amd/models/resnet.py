@@ -43,12 +43,16 @@ class Bottleneck(nn.Module):
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = FusedBatchNormAct(planes * 4)
         self.downsample = downsample
+        self.fork = False            # True: the output goes to a next block, as a (main branch, skip connection) pair
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x))                    # batch norm + ReLU: one operator (ops/batchnorm.py)
+        # a preceding block hands its output over as two handles of one tensor, so that the gradients of the two uses
+        # reach its last batch norm separately and are added inside that layer's backward kernel
+        main, skip = x if isinstance(x, tuple) else (x, x)
+        idt = skip if self.downsample is None else self.downsample(skip)
+        out = self.bn1(self.conv1(main))                 # batch norm + ReLU: one operator (ops/batchnorm.py)
         out = self.bn2(self.conv2(out))
-        return self.bn3(self.conv3(out), residual=idt)   # batch norm + residual + ReLU
+        return self.bn3(self.conv3(out), residual=idt, fork=self.fork)   # batch norm + residual + ReLU
 
 
 class ResNet(nn.Module):
@@ -62,6 +66,9 @@ class ResNet(nn.Module):
         self.layer3 = self._make(width * 4, layers[2], 2)
         self.layer4 = self._make(width * 8, layers[3], 2)
         self.fc = nn.Linear(width * 8 * 4, num_classes)
+        blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
+        for b in blocks[:-1]:
+            b.fork = True
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -116,6 +123,31 @@ class TorchModuleProgram:
             p.data = flat
             p.grad = self.state.grad(n)
         self.state.initialized = True
+        # One worker on a GPU: autograd hands the gradient tensors over (``p.grad`` is None when the backward pass
+        # starts, nothing is accumulated) and a few multi-tensor copies move them into the flat gradient buffer, where
+        # the preassigned gradient views cost one add kernel per parameter and step.  Convolutions then read
+        # persistent compute-precision copies of their weights, refreshed by one multi-tensor copy per step, instead of
+        # casting every weight in the forward pass and its gradient back in the backward pass (autocast).  With the
+        # gradient hooks of the bucketed aggregation (several workers) the gradients must be in the flat buffer when a
+        # hook fires: that path keeps the preassigned views.  DTF_DIRECT_GRADS=0 selects it everywhere.
+        self.direct_grads = self.device.type == "cuda" and os.environ.get("DTF_DIRECT_GRADS", "1") != "0"
+        self._direct_now = False
+        self._params = [p for _, p in named]
+        self._grad_views = [self.state.grad(n) for n, _ in named]
+        self._copies = {}                       # id(master parameter) -> compute-precision leaf the convolution reads
+        if self.direct_grads and autocast is not None:
+            fmt = torch.channels_last if (channels_last and images.dim() == 4) else torch.contiguous_format
+            for m in self.module.modules():
+                if isinstance(m, nn.Conv2d) and m.bias is None and m.padding_mode == "zeros":
+                    w = torch.empty_like(m.weight, dtype=autocast, memory_format=fmt).requires_grad_(True)
+                    self._copies[id(m.weight)] = w
+                    m.forward = self._conv_forward(m, w)
+        # the batch counters of all batch-norm layers advance by one multi-tensor add per step, not one launch per layer
+        self._bn_counters = []
+        for m in self.module.modules():
+            if isinstance(m, FusedBatchNormAct) and m.num_batches_tracked is not None:
+                m.count_batches = False
+                self._bn_counters.append(m.num_batches_tracked)
         self.images, self.labels = images.to(self.device), labels.to(self.device)
         if channels_last and self.images.dim() == 4:
             self.images = self.images.contiguous(memory_format=torch.channels_last)
@@ -145,6 +177,29 @@ class TorchModuleProgram:
         self._last = torch.zeros(2, dtype=torch.float32, device=self.device)                  # ... of the step just run
         self._last_gs = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.gs_log = torch.zeros(log_capacity, dtype=torch.int32, device=self.device)
+
+    def _conv_forward(self, m: nn.Conv2d, w: torch.Tensor):
+        def forward(x):
+            if self._direct_now:
+                return m._conv_forward(x, w, None)
+            return nn.Conv2d.forward(m, x)
+        return forward
+
+    def _gradients_to_flat(self) -> None:
+        """After a backward pass in direct mode: every parameter's gradient (of its compute copy, where it has one)
+        into its view of the flat gradient buffer, grouped by source dtype (multi-tensor copies)."""
+        by_dtype = {}
+        for p, view in zip(self._params, self._grad_views):
+            leaf = self._copies.get(id(p), p)
+            g = leaf.grad
+            if g is None:
+                view.zero_()                    # took no part in this step
+                continue
+            dst, src = by_dtype.setdefault(g.dtype, ([], []))
+            dst.append(view)
+            src.append(g)
+        for dst, src in by_dtype.values():
+            torch._foreach_copy_(dst, src)
 
     def grad_groups(self):
         """Gradient buckets (consecutive parameters, layout order) and the hooks that report them complete."""
@@ -193,7 +248,22 @@ class TorchModuleProgram:
 
     def _step_body(self, x, y) -> None:
         """The device work of one step; touches no host state, so it can be captured and replayed."""
-        self.state.grads.zero_()
+        self._direct_now = direct = self.direct_grads and self.grad_ready is None and self._groups is None
+        if direct:
+            if self._copies:
+                leaves = list(self._copies.values())
+                with torch.no_grad():
+                    torch._foreach_copy_(leaves, [p for p in self._params if id(p) in self._copies])
+                for w in leaves:
+                    w.grad = None
+            for p in self._params:
+                p.grad = None
+        else:
+            for p, view in zip(self._params, self._grad_views):
+                p.grad = view
+            self.state.grads.zero_()
+        if self._bn_counters:
+            torch._foreach_add_(self._bn_counters, 1)
         if self.fused_head:
             # classifier + loss + accuracy count: one autograd node on the framework's own kernels
             with torch.autocast(self.device.type, dtype=self.autocast, enabled=self.autocast is not None):
@@ -209,6 +279,8 @@ class TorchModuleProgram:
             loss.backward()
             self._last[0:1].copy_(loss.detach().reshape(1))
             self._last[1:2].copy_((logits.argmax(1) == y).sum().float().reshape(1))
+        if direct:
+            self._gradients_to_flat()
         self._last_gs.copy_(self.state.state[0:1])
         if self.after_compute is not None:
             self.after_compute()

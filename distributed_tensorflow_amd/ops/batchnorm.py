@@ -42,7 +42,7 @@ def _kernels():
         lib.dtf_bn_fwd.restype = C.c_int
         lib.dtf_bn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, fp, fp, vp]
         lib.dtf_bn_bwd.restype = C.c_int
-        lib.dtf_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]
+        lib.dtf_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]
         _protos_done = True
     return lib
 
@@ -84,7 +84,7 @@ def reference_bn_act(x, weight, bias, running_mean, running_var, residual, relu,
 
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, residual, relu, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, relu, momentum, eps, fork=False):
         lib = _kernels()
         m, ch = _nhwc_rows(x), x.shape[1]
         if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
@@ -102,37 +102,57 @@ class _BnAct(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, y if ctx.mask == 2 else None, save)
         ctx.wdtype, ctx.bdtype = weight.dtype, bias.dtype
+        if fork:
+            # two handles of one output: the gradients of its two consumers then reach backward() separately, and
+            # the reduction kernel adds them while it reads them (no addition kernel of autograd's in front)
+            ctx.set_materialize_grads(False)
+            return y, y.detach()
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         lib = _kernels()
         x, y, save = ctx.saved_tensors
         m, ch = _nhwc_rows(x), x.shape[1]
-        if dy.dtype != x.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
-            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+
+        def dense(g):
+            if g.dtype != x.dtype or not g.is_contiguous(memory_format=torch.channels_last):
+                g = g.to(x.dtype).contiguous(memory_format=torch.channels_last)
+            return g
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
+            return (None,) * 10
+        dy = dense(dy)
+        if dy2 is not None:
+            dy2 = dense(dy2)
+            if ctx.mask != 2:
+                dy, dy2 = dy + dy2, None                          # the kernels add only in front of the ReLU mask of a residual layer
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.mask == 2 else None
         dgb = torch.empty(2 * ch, dtype=torch.float32, device=x.device)
         coef = torch.empty(3 * ch, dtype=torch.float32, device=x.device)
-        _lib.check(lib.dtf_bn_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr() if y is not None else None, dx.data_ptr(),
+        _lib.check(lib.dtf_bn_bwd(dy.data_ptr(), dy2.data_ptr() if dy2 is not None else None, x.data_ptr(),
+                                  y.data_ptr() if y is not None else None, dx.data_ptr(),
                                   dres.data_ptr() if dres is not None else None, save.data_ptr(), dgb.data_ptr(),
                                   dgb.data_ptr() + 4 * ch, _workspace(x.device, ch).data_ptr(), coef.data_ptr(), m, ch,
                                   ctx.mask, _lib.stream_handle()), "bn_bwd")
         if ctx.has_res and dres is None:
             dres = dy                                             # no activation: the residual input sees dy itself
         return (dx, dgb[:ch].to(ctx.wdtype), dgb[ch:].to(ctx.bdtype), None, None, dres if ctx.has_res else None,
-                None, None, None)
+                None, None, None, None)
 
 
 def bn_act(x, weight, bias, running_mean=None, running_var=None, residual=None, relu=True, training=True,
-           momentum=0.1, eps=1e-5):
-    """``act(batch_norm(x) [+ residual])`` with the batch statistics of ``x`` (training) or the running ones."""
+           momentum=0.1, eps=1e-5, fork=False):
+    """``act(batch_norm(x) [+ residual])`` with the batch statistics of ``x`` (training) or the running ones.
+    ``fork``: the result as a pair of handles for two consumers (a block's main branch and its skip connection)."""
     takes = kernel_path_takes(x, residual, training)
     calls["kernel" if takes else "operators"] += 1
     if takes:
-        return _BnAct.apply(x, weight, bias, running_mean, running_var, residual, relu, momentum, eps)
-    return reference_bn_act(x, weight, bias, running_mean, running_var, residual, relu, training, momentum, eps)
+        return _BnAct.apply(x, weight, bias, running_mean, running_var, residual, relu, momentum, eps, fork)
+    y = reference_bn_act(x, weight, bias, running_mean, running_var, residual, relu, training, momentum, eps)
+    return (y, y) if fork else y
 
 
 class FusedBatchNormAct(nn.BatchNorm2d):
@@ -141,10 +161,11 @@ class FusedBatchNormAct(nn.BatchNorm2d):
     def __init__(self, num_features, relu: bool = True, eps: float = 1e-5, momentum: float = 0.1):
         super().__init__(num_features, eps=eps, momentum=momentum)
         self.relu = relu
+        self.count_batches = True       # False: the owner of the model advances ``num_batches_tracked`` of all layers at once
 
-    def forward(self, x, residual=None):                          # noqa: D102
+    def forward(self, x, residual=None, fork=False):              # noqa: D102
         training = self.training or self.running_mean is None
-        if training and self.num_batches_tracked is not None:
+        if training and self.count_batches and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
         return bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, residual, self.relu, training,
-                      self.momentum, self.eps)
+                      self.momentum, self.eps, fork)

@@ -82,3 +82,45 @@ def test_large_activation_statistics():
     assert torch.allclose(rv, var, rtol=1e-3, atol=1e-5)
     yf = y.float()
     assert float(yf.mean(dim=(0, 2, 3)).abs().max()) < 2e-2 and float((yf.var(dim=(0, 2, 3)) - 1).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("residual,relu,use", [(True, True, "both"), (True, True, "first"), (True, True, "second"),
+                                               (False, True, "both"), (True, False, "both")])
+def test_forked_output_adds_the_two_gradients_in_the_kernel(residual, relu, use):
+    """``fork=True``: two handles of one output; their gradients reach the backward pass separately and the sum is
+    formed inside the reduction kernel (residual + ReLU layers) or in front of it (other layers)."""
+    n, c, h, w = 6, 128, 9, 7
+    x, res, dy, gamma, beta = _inputs(n, c, h, w, seed=3, residual=residual)
+    dy2 = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(9)).bfloat16().contiguous(memory_format=torch.channels_last)
+    w1 = 1.0 if use in ("both", "first") else 0.0
+    w2 = 1.0 if use in ("both", "second") else 0.0
+    xr = x.float().requires_grad_(True)
+    rr = res.float().requires_grad_(True) if residual else None
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    want = bn.reference_bn_act(xr, gr, br, torch.zeros(c), torch.ones(c), rr, relu, True, 0.1, 1e-5)
+    want.backward(w1 * dy.float() + w2 * dy2.float())
+
+    xg = x.to(DEV).requires_grad_(True)
+    rg = res.to(DEV).requires_grad_(True) if residual else None
+    gg, bg = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    a, b = bn.bn_act(xg, gg, bg, torch.zeros(c, device=DEV), torch.ones(c, device=DEV), rg, relu, True, 0.1, 1e-5, fork=True)
+    assert a.data_ptr() == b.data_ptr()
+    outs, grads = [], []
+    if w1:
+        outs.append(a), grads.append(dy.to(DEV))
+    if w2:
+        outs.append(b), grads.append(dy2.to(DEV))
+    torch.autograd.backward(outs, grads)
+
+    def close(p, q, rtol, atol):
+        p, q = p.detach().float().cpu(), q.detach().float().cpu()
+        assert torch.allclose(p, q, rtol=rtol, atol=atol), float((p - q).abs().max())
+    m = n * h * w
+    close(a, want, 1e-2, 1e-2)
+    # outside residual + ReLU layers the sum of the two gradients is rounded to bf16 before the kernels see it
+    loose = 1.0 if (residual and relu) else 4.0
+    close(gg.grad, gr.grad, 1e-3, loose * 3e-3 * m ** 0.5)
+    close(bg.grad, br.grad, 1e-3, loose * 3e-3 * m ** 0.5)
+    close(xg.grad, xr.grad, 2e-2, 3e-2)
+    if residual:
+        close(rg.grad, rr.grad, 1e-2, 2e-2)
