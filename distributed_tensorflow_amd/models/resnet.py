@@ -27,6 +27,7 @@ import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct
 from ..ops.classifier import linear_xent
+from ..ops.maxpool import max_pool2d
 from ..parallel.sharded_state import ShardedState, VariableSpec
 from .mlp import StepRecord
 
@@ -88,7 +89,7 @@ class ResNet(nn.Module):
         classifier and loss as one node on the framework's GEMM and softmax cross-entropy kernels
         (``ops/classifier.linear_xent`` with ``self.fc``'s parameters)."""
         x = self.bn1(self.conv1(x))
-        x = F.max_pool2d(x, 3, stride=2, padding=1)
+        x = max_pool2d(x, 3, 2, 1)                       # own kernels on the GPU (ops/maxpool.py)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
         return x if features_only else self.fc(x)
