@@ -308,6 +308,7 @@ def bench_resnet50_sync(args, rank, world, device):
     from .models.resnet import TorchModuleProgram, resnet50
     from .ops.batchnorm import calls as bn_calls
     from .ops.classifier import calls as head_calls
+    from .ops.maxpool import calls as pool_calls
     batch = args.batch_size or 256
     optimizer = args.optimizer or "adam"
     dtype_name = args.dtype or "bf16"
@@ -345,7 +346,10 @@ def bench_resnet50_sync(args, rank, world, device):
                                   if head_calls["kernel"] and not head_calls["operators"]
                                   else "PyTorch operators" if not head_calls["kernel"] else "mixed"),
                    "batch_norm": ("fused kernels (batchnorm.hip)" if bn_calls["kernel"] and not bn_calls["operators"]
-                                  else "PyTorch operators" if not bn_calls["kernel"] else "mixed")},
+                                  else "PyTorch operators" if not bn_calls["kernel"] else "mixed"),
+                   "max_pool": "own kernels (maxpool.hip)" if pool_calls["kernel"] else "PyTorch operator",
+                   "gradients": ("handed over by autograd, multi-tensor copies into the flat buffer, bf16 weight copies"
+                                 if prog._direct_now else "accumulated into views of the flat buffer")},
         "final_loss": last.loss,
     }
 
