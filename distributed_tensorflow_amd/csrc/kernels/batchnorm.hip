@@ -4,11 +4,12 @@
 //     y = act(gamma * (x - mean) * rstd + beta [+ residual])            x, y, residual: [M, C] bf16, M = N*H*W
 //
 // As three operators (batch norm, add, ReLU) a layer costs 13 tensor-sized memory passes per training step without
-// a residual and 16 with one; here 8 and 11:
-//   forward   stats (read x) -> finalize ([C]) -> normalize (read x [, residual], write y)
-//   backward  reduce (read dy, x [, y]; write the masked dy when a residual branch needs it) -> finalize ([C])
+// a residual and 16 with one; here 8 and 10:
+//   forward   stats (read x) -> finalize ([C]) -> normalize (read x [, residual], write y [, mask bits])
+//   backward  reduce (read dy, x [, mask bits]; write the masked dy when a residual branch needs it) -> finalize ([C])
 //             -> dx (read dy, x; write dx)
-// The ReLU mask of the backward pass is recomputed from x (no residual) or read from y (residual).
+// The ReLU mask of the backward pass is recomputed from x (no residual) or read as one bit per element that the
+// forward pass stored (residual: 1/16 of a tensor pass instead of reading y again).
 //
 // Layout: a thread owns 8 consecutive channels (one 16-byte load per row) and walks rows with a grid stride;
 // C/8 threads cover a row, so a 256-thread block takes 256/(C/8) rows per iteration and every wave reads whole
@@ -171,10 +172,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_finalize_fwd_kernel(const float
   }
 }
 
+// bits (residual + ReLU layers): one byte per thread and row, bit j = (output of channel c0 + j is positive): the
+// backward pass reads these M * C / 8 bytes instead of the 2 * M * C bytes of y for its ReLU mask.
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
-                                                               unsigned short* __restrict__ y, const float* __restrict__ save,
-                                                               int64_t M, int C) {
+                                                               unsigned short* __restrict__ y, unsigned char* __restrict__ bits,
+                                                               const float* __restrict__ save, int64_t M, int C) {
   const Walk w = make_walk(C);
   float a[8], b[8];
 #pragma unroll
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const unsigned sho
       float v[8], rv[8];
       unpack8(q[u], v);
       if (RES) unpack8(qr[u], rv);
+      unsigned m = 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float o = v[j] * a[j] + b[j];
@@ -202,14 +206,23 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const unsigned sho
         if (RELU) o = o > 0.f ? o : 0.f;
         v[j] = o;
       }
-      st16(y, (size_t)rr * C + w.c0, pack8(v));
+      const u32x4 packed = pack8(v);
+      if (RES && RELU) {
+        // the mask of the backward pass is "the bf16 output is positive": taken from the rounded values
+        float rnd[8];
+        unpack8(packed, rnd);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m |= (rnd[j] > 0.f ? 1u : 0u) << j;
+        if (bits) bits[(size_t)rr * (C >> 3) + (w.c0 >> 3)] = (unsigned char)m;
+      }
+      st16(y, (size_t)rr * C + w.c0, packed);
     }
   }
 }
 
 // ---- backward ----
-// MASK: 0 = no activation, 1 = ReLU without residual (sign of a*x + b), 2 = ReLU after a residual (y > 0; the
-// masked dy is written to dres: it is the gradient of the residual branch and the dx kernel's input).
+// MASK: 0 = no activation, 1 = ReLU without residual (sign of a*x + b), 2 = ReLU after a residual (the forward
+// pass's mask bits; the masked dy is written to dres: it is the gradient of the residual branch and the dx kernel's input).
 // Partials: sum(dym) and sum(dym * (x - mean)).
 // SUM2 (with MASK 2 only): the output went to two consumers (the next block's main branch and its skip connection) and
 // their gradients arrive separately; dy = dy + dy2 is formed here in fp32 instead of by an addition kernel of its own
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const unsigned sho
 template <int MASK, bool SUM2>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ dy2,
                                                                     const unsigned short* __restrict__ x,
-                                                                    const unsigned short* __restrict__ y, unsigned short* __restrict__ dres,
+                                                                    const unsigned char* __restrict__ bits, unsigned short* __restrict__ dres,
                                                                     const float* __restrict__ save, int64_t M, int C,
                                                                     float* __restrict__ part) {
   const Walk w = make_walk(C);
@@ -229,7 +242,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const unsigne
     s[j] = sx[j] = 0.f;
   }
   for (int64_t r = w.row; r < M; r += w.step * kUnroll) {
-    u32x4 qd[kUnroll], qd2[kUnroll], qx[kUnroll], qy[kUnroll];
+    u32x4 qd[kUnroll], qd2[kUnroll], qx[kUnroll];
+    unsigned mb[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t rr = r + u * w.step;
@@ -238,22 +252,21 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const unsigne
       qd[u] = ok ? (MASK == 2 ? ld16_last(dy, e) : ld16(dy, e)) : u32x4{0u, 0u, 0u, 0u};   // (MASK 2: dx reads dres instead)
       if (SUM2) qd2[u] = ok ? ld16_last(dy2, e) : u32x4{0u, 0u, 0u, 0u};
       qx[u] = ok ? ld16(x, e) : u32x4{0u, 0u, 0u, 0u};
-      if (MASK == 2) qy[u] = ok ? ld16_last(y, e) : u32x4{0u, 0u, 0u, 0u};
+      if (MASK == 2) mb[u] = ok ? (unsigned)bits[(size_t)rr * (C >> 3) + (w.c0 >> 3)] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t rr = r + u * w.step;
       if (rr >= M) continue;
-      float d[8], d2[8], xv[8], yv[8];
+      float d[8], d2[8], xv[8];
       unpack8(qd[u], d);
       if (SUM2) unpack8(qd2[u], d2);
       unpack8(qx[u], xv);
-      if (MASK == 2) unpack8(qy[u], yv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (SUM2) d[j] += d2[j];
         if (MASK == 1) d[j] = (xv[j] * a[j] + b[j]) > 0.f ? d[j] : 0.f;
-        if (MASK == 2) d[j] = yv[j] > 0.f ? d[j] : 0.f;
+        if (MASK == 2) d[j] = ((mb[u] >> j) & 1u) ? d[j] : 0.f;
         s[j] += d[j];
         sx[j] += d[j] * (xv[j] - mean[j]);
       }
@@ -349,11 +362,13 @@ DTF_EXPORT int64_t dtf_bn_workspace_floats(int C) { return (int64_t)2 * kBnMaxBl
 
 DTF_EXPORT int dtf_bn_supported(int64_t M, int C) { return bn_shape_ok(M, C) ? 1 : 0; }
 
-// y = act(bn(x) [+ res]); save [4][C] receives mean, rstd and the folded scale / shift for the backward pass.
-DTF_EXPORT int dtf_bn_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta, float* running_mean,
+// y = act(bn(x) [+ res]); save [4][C] receives mean, rstd and the folded scale / shift for the backward pass;
+// bits [M * C / 8] bytes (required with res and relu) the ReLU mask the backward pass reads.
+DTF_EXPORT int dtf_bn_fwd(const void* x, const void* res, void* y, void* bits, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, float* save, float* part, int64_t M, int C, int relu, float momentum, float eps,
                           hipStream_t s) {
   if (!x || !y || !gamma || !beta || !save || !part) return DTF_ERR_ARG;
+  if (res && relu && !bits) return DTF_ERR_ARG;
   if (!bn_shape_ok(M, C)) return DTF_ERR_SHAPE;
   if (!dtf_aligned16(x) || !dtf_aligned16(y) || (res && !dtf_aligned16(res))) return DTF_ERR_ALIGN;
   if ((running_mean == nullptr) != (running_var == nullptr)) return DTF_ERR_ARG;
@@ -362,39 +377,40 @@ DTF_EXPORT int dtf_bn_fwd(const void* x, const void* res, void* y, const float* 
   const auto* xs = static_cast<const unsigned short*>(x);
   const auto* rs = static_cast<const unsigned short*>(res);
   auto* ys = static_cast<unsigned short*>(y);
+  auto* bs = static_cast<unsigned char*>(bits);
   hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(kBnThreads), 0, s, xs, M, C, part);
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(dtf_cdiv(C, 4)), dim3(kBnThreads), 0, s, part, nblk, M, C, gamma, beta, running_mean,
                      running_var, save, momentum, eps);
-  if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(kBnThreads), 0, s, xs, rs, ys, save, M, C);
-  else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(kBnThreads), 0, s, xs, rs, ys, save, M, C);
-  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, dim3(kBnThreads), 0, s, xs, rs, ys, save, M, C);
-  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(kBnThreads), 0, s, xs, rs, ys, save, M, C);
+  if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(kBnThreads), 0, s, xs, rs, ys, bs, save, M, C);
+  else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(kBnThreads), 0, s, xs, rs, ys, bs, save, M, C);
+  else if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, dim3(kBnThreads), 0, s, xs, rs, ys, bs, save, M, C);
+  else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(kBnThreads), 0, s, xs, rs, ys, bs, save, M, C);
   return dtf_check_launch();
 }
 
-// Backward of the above.  mask: 0 none, 1 ReLU recomputed from x, 2 ReLU read from y (then `y` and `dres` are
-// required and dres receives the masked dy = the gradient of the residual input).  coef: [3][C] scratch.
+// Backward of the above.  mask: 0 none, 1 ReLU recomputed from x, 2 ReLU from the forward pass's mask bits (then `bits`
+// and `dres` are required and dres receives the masked dy = the gradient of the residual input).  coef: [3][C] scratch.
 // dy2 (optional, mask 2 only): a second gradient of the same output; the layer's dy is dy + dy2.
-DTF_EXPORT int dtf_bn_bwd(const void* dy, const void* dy2, const void* x, const void* y, void* dx, void* dres, const float* save,
+DTF_EXPORT int dtf_bn_bwd(const void* dy, const void* dy2, const void* x, const void* bits, void* dx, void* dres, const float* save,
                           float* dgamma, float* dbeta, float* part, float* coef, int64_t M, int C, int mask, hipStream_t s) {
   if (!dy || !x || !dx || !save || !dgamma || !dbeta || !part || !coef) return DTF_ERR_ARG;
-  if (mask < 0 || mask > 2 || (mask == 2 && (!y || !dres)) || (dy2 && mask != 2)) return DTF_ERR_ARG;
+  if (mask < 0 || mask > 2 || (mask == 2 && (!bits || !dres)) || (dy2 && mask != 2)) return DTF_ERR_ARG;
   if (dy2 && !dtf_aligned16(dy2)) return DTF_ERR_ALIGN;
   if (!bn_shape_ok(M, C)) return DTF_ERR_SHAPE;
-  if (!dtf_aligned16(dy) || !dtf_aligned16(x) || !dtf_aligned16(dx) || (mask == 2 && (!dtf_aligned16(y) || !dtf_aligned16(dres))))
+  if (!dtf_aligned16(dy) || !dtf_aligned16(x) || !dtf_aligned16(dx) || (mask == 2 && !dtf_aligned16(dres)))
     return DTF_ERR_ALIGN;
   const dim3 grid = bn_grid(M, C);
   const int nblk = (int)grid.x;
   const auto* ds = static_cast<const unsigned short*>(dy);
   const auto* ds2 = static_cast<const unsigned short*>(dy2);
   const auto* xs = static_cast<const unsigned short*>(x);
-  const auto* ys = static_cast<const unsigned short*>(y);
+  const auto* mbits = static_cast<const unsigned char*>(bits);
   auto* dxs = static_cast<unsigned short*>(dx);
   auto* drs = static_cast<unsigned short*>(dres);
-  if (mask == 2 && ds2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<2, true>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, ys, drs, save, M, C, part);
-  else if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<2, false>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, ys, drs, save, M, C, part);
-  else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, false>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, ys, drs, save, M, C, part);
-  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<0, false>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, ys, drs, save, M, C, part);
+  if (mask == 2 && ds2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<2, true>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, mbits, drs, save, M, C, part);
+  else if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<2, false>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, mbits, drs, save, M, C, part);
+  else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, false>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, mbits, drs, save, M, C, part);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<0, false>), grid, dim3(kBnThreads), 0, s, ds, ds2, xs, mbits, drs, save, M, C, part);
   hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(dtf_cdiv(C, 4)), dim3(kBnThreads), 0, s, part, nblk, M, C, save, dgamma, dbeta, coef);
   if (mask == 2) hipLaunchKernelGGL(bn_bwd_dx_kernel<0>, grid, dim3(kBnThreads), 0, s, drs, xs, dxs, save, coef, M, C);
   else if (mask == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<1>, grid, dim3(kBnThreads), 0, s, ds, xs, dxs, save, coef, M, C);

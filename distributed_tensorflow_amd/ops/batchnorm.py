@@ -5,7 +5,7 @@
     y = act(batch_norm(x) [+ residual])
 
 On a GPU, in training mode, with bf16 channels-last activations of 8 * 2^k channels, forward and backward are
-three launches each of the hand-written kernels: 8 tensor-sized memory passes per layer and training step (11
+three launches each of the hand-written kernels: 8 tensor-sized memory passes per layer and training step (10
 with a residual) instead of the 13 (16) of the operator sequence batch_norm / add / relu.  Everything else (CPU, fp32, evaluation mode,
 other layouts) is that operator sequence, which is also the test oracle.  ``DTF_FUSED_BN=0`` forces the operator
 sequence.
@@ -40,7 +40,7 @@ def _kernels():
         lib.dtf_bn_supported.restype = C.c_int
         lib.dtf_bn_supported.argtypes = [C.c_int64, C.c_int]
         lib.dtf_bn_fwd.restype = C.c_int
-        lib.dtf_bn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, fp, fp, vp]
+        lib.dtf_bn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, fp, fp, vp]
         lib.dtf_bn_bwd.restype = C.c_int
         lib.dtf_bn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]
         _protos_done = True
@@ -92,15 +92,17 @@ class _BnAct(torch.autograd.Function):
         y = torch.empty_like(x)                                   # keeps the channels-last strides
         save = torch.empty(4 * ch, dtype=torch.float32, device=x.device)
         w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        # residual + ReLU: the mask of the backward pass as one bit per element (the kernels then never read y again)
+        bits = torch.empty(m * ch // 8, dtype=torch.uint8, device=x.device) if (relu and residual is not None) else None
         _lib.check(lib.dtf_bn_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(),
-                                  w32.data_ptr(), b32.data_ptr(),
+                                  bits.data_ptr() if bits is not None else None, w32.data_ptr(), b32.data_ptr(),
                                   running_mean.data_ptr() if running_mean is not None else None,
                                   running_var.data_ptr() if running_var is not None else None,
                                   save.data_ptr(), _workspace(x.device, ch).data_ptr(), m, ch, 1 if relu else 0,
                                   float(momentum), float(eps), _lib.stream_handle()), "bn_fwd")
         ctx.mask = 0 if not relu else (2 if residual is not None else 1)
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, y if ctx.mask == 2 else None, save)
+        ctx.save_for_backward(x, bits, save)
         ctx.wdtype, ctx.bdtype = weight.dtype, bias.dtype
         if fork:
             # two handles of one output: the gradients of its two consumers then reach backward() separately, and
@@ -112,7 +114,7 @@ class _BnAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dy2=None):
         lib = _kernels()
-        x, y, save = ctx.saved_tensors
+        x, bits, save = ctx.saved_tensors
         m, ch = _nhwc_rows(x), x.shape[1]
 
         def dense(g):
@@ -133,7 +135,7 @@ class _BnAct(torch.autograd.Function):
         dgb = torch.empty(2 * ch, dtype=torch.float32, device=x.device)
         coef = torch.empty(3 * ch, dtype=torch.float32, device=x.device)
         _lib.check(lib.dtf_bn_bwd(dy.data_ptr(), dy2.data_ptr() if dy2 is not None else None, x.data_ptr(),
-                                  y.data_ptr() if y is not None else None, dx.data_ptr(),
+                                  bits.data_ptr() if bits is not None else None, dx.data_ptr(),
                                   dres.data_ptr() if dres is not None else None, save.data_ptr(), dgb.data_ptr(),
                                   dgb.data_ptr() + 4 * ch, _workspace(x.device, ch).data_ptr(), coef.data_ptr(), m, ch,
                                   ctx.mask, _lib.stream_handle()), "bn_bwd")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fused batch norm + residual + ReLU (csrc/kernels/batchnorm.hip) against PyTorch's batch_norm / add / relu on the
 activation shapes of ResNet-50 at batch 256 (channels-last bf16): forward + backward time per call and the
-bandwidth the fused path reaches on its tensor passes (8 per call, 11 with a residual).
+bandwidth the fused path reaches on its tensor passes (8 per call, 10 with a residual).
 
     python tools/bn_bench.py [--batch 256] [--iters 20]
 """
@@ -53,9 +53,9 @@ for c, hw, residual in SHAPES:
     b = torch.zeros(c, device=dev, requires_grad=True)
     rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
     mb = x.numel() * 2 / 1e6
-    # tensor passes of the fused path: forward stats 1, apply 2 (+1: residual); backward reduce 2 (+2: y, masked dy),
-    # dx 3
-    passes = 8 + (3 if residual else 0)
+    # tensor passes of the fused path: forward stats 1, apply 2 (+1: residual); backward reduce 2 (+1: masked dy;
+    # the mask bits are 1/16 of a pass each way), dx 3
+    passes = 8 + (2.125 if residual else 0)
     tf = run(bn.bn_act, x, res, w, b, rm, rv, dy, a.iters)
     if a.only_fused:
         print(f"{c:5d} {hw:4d}x{hw:<3d} {str(residual)[0]:>4} {mb:7.1f} {tf:9.1f}")
