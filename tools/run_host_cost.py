@@ -68,3 +68,27 @@ rs = sorted(whole() for _ in range(200))
 print("engine.run(20) + synchronize: host %.1f us, total %.1f us (median of 200)" % (rs[100][0], sorted(r[1] for r in rs)[100]))
 t = sorted(timed(lambda: torch.cuda.synchronize(), reps=1) for _ in range(200))[100]
 print("synchronize on an idle stream %.2f us" % t)
+
+# experiment: the first k steps of a run as direct kernel launches (the device starts ~4 us after the first call), the
+# rest as ONE graph launched while they run (its ~12 us start-up latency hidden behind them)
+for k in (0, 1, 2, 3, 4):
+    def split_run():
+        prog._pipe_open()
+        prog.data.prepare(prog.steps_enqueued, N + 3, 100)
+        for _ in range(k):
+            prog._pipe_step()
+        prog._graph_for(N - k, last=True).replay()
+        prog.steps_enqueued += N - k
+        prog._pipe_close(launched=True)
+    for _ in range(3):
+        split_run()
+        torch.cuda.synchronize()
+    ts = []
+    for _ in range(200):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        split_run()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e6)
+    ts.sort()
+    print("first %d steps direct + graph of %d: total %.1f us (median of 200), min %.1f" % (k, N - k, ts[100], ts[0]))
