@@ -99,6 +99,42 @@ def resnet50(num_classes=1000, width=64, layers=(3, 4, 6, 3)) -> ResNet:
     return ResNet(layers, num_classes, width)
 
 
+class _ConvWgradAside(torch.autograd.Function):
+    """A convolution whose backward pass computes the weight gradient on a second stream.
+
+    In the backward pass of a ResNet the chain that the next layer waits for is (batch-norm backward -> data
+    gradient of the convolution); the weight gradient is needed only when the optimizer runs.  Its kernels (and the
+    library's zero-fill / cast helpers around them) go to a side stream, where they run beside the bandwidth-bound
+    batch-norm kernels of the main chain and fill the gaps between its dependent launches.  The owner of the side
+    stream joins it before it reads the gradients (``TorchModuleProgram._gradients_to_flat``)."""
+
+    @staticmethod
+    def forward(ctx, x, w, conv, side):
+        if x.dtype != w.dtype:
+            x = x.to(w.dtype)                               # (what autocast does with the network's fp32 input)
+        ctx.save_for_backward(x, w)
+        ctx.conv, ctx.side = conv, side
+        return conv._conv_forward(x, w, None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        m, side = ctx.conv, ctx.side
+        args = (None, m.stride, m.padding, m.dilation, False, [0, 0], m.groups)
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            main = torch.cuda.current_stream(gy.device)
+            side.wait_stream(main)                          # gy exists from here on
+            with torch.cuda.stream(side):
+                gw = torch.ops.aten.convolution_backward(gy, x, w, *args, [False, True, False])[1]
+            # their memory must not be handed out again on the main stream while the side stream still reads it
+            gy.record_stream(side)
+            x.record_stream(side)
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w, *args, [True, False, False])[0]
+        return gx, gw, None, None
+
+
 class TorchModuleProgram:
     """Step program around a PyTorch module whose parameters live in a ``ShardedState``.
 
@@ -136,6 +172,9 @@ class TorchModuleProgram:
         self._params = [p for _, p in named]
         self._grad_views = [self.state.grad(n) for n, _ in named]
         self._copies = {}                       # id(master parameter) -> compute-precision leaf the convolution reads
+        # weight gradients of the convolutions on a second stream (DTF_WGRAD_STREAM=0: on the main stream)
+        self._side = (torch.cuda.Stream(self.device)
+                      if self.direct_grads and os.environ.get("DTF_WGRAD_STREAM", "1") != "0" else None)
         if self.direct_grads and autocast is not None:
             fmt = torch.channels_last if (channels_last and images.dim() == 4) else torch.contiguous_format
             for m in self.module.modules():
@@ -182,6 +221,8 @@ class TorchModuleProgram:
     def _conv_forward(self, m: nn.Conv2d, w: torch.Tensor):
         def forward(x):
             if self._direct_now:
+                if self._side is not None and torch.is_grad_enabled():
+                    return _ConvWgradAside.apply(x, w, m, self._side)
                 return m._conv_forward(x, w, None)
             return nn.Conv2d.forward(m, x)
         return forward
@@ -189,6 +230,8 @@ class TorchModuleProgram:
     def _gradients_to_flat(self) -> None:
         """After a backward pass in direct mode: every parameter's gradient (of its compute copy, where it has one)
         into its view of the flat gradient buffer, grouped by source dtype (multi-tensor copies)."""
+        if self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)      # the weight gradients are complete
         by_dtype = {}
         for p, view in zip(self._params, self._grad_views):
             leaf = self._copies.get(id(p), p)
