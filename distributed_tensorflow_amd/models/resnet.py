@@ -201,7 +201,8 @@ class TorchModuleProgram:
         self.fused_head = isinstance(self.module, ResNet) and os.environ.get("DTF_FUSED_HEAD", "1") != "0"
         # DTF_MODULE_GRAPH=1, one rank on a GPU: the whole step (forward, backward, optimizer) is captured into a
         # hipGraph after three eager steps and replayed; the host then only copies the next batch into the graph's
-        # input buffers.  Opt-in: the ResNet-50 step is bound by the GPU (26.81 ms replayed, 26.97 ms eager).
+        # input buffers.  Opt-in: the ResNet-50 step is bound by the GPU (26.81 ms replayed, 26.97 ms eager on one stream; with the weight
+        # gradients on a second stream the eager step is the faster one, 25.9 against 26.7 ms).
         self.use_graphs = (self.device.type == "cuda" and world_size == 1 and os.environ.get("DTF_MODULE_GRAPH", "0") == "1")
         self._graphs = {}
         self._graph = None
