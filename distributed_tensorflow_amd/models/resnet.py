@@ -231,8 +231,9 @@ class TorchModuleProgram:
     def _gradients_to_flat(self) -> None:
         """After a backward pass in direct mode: every parameter's gradient (of its compute copy, where it has one)
         into its view of the flat gradient buffer, grouped by source dtype (multi-tensor copies)."""
+        cur = torch.cuda.current_stream(self.device)
         if self._side is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._side)      # the weight gradients are complete
+            cur.wait_stream(self._side)                     # the weight gradients are complete
         by_dtype = {}
         for p, view in zip(self._params, self._grad_views):
             leaf = self._copies.get(id(p), p)
@@ -240,6 +241,8 @@ class TorchModuleProgram:
             if g is None:
                 view.zero_()                    # took no part in this step
                 continue
+            if self._side is not None and id(p) in self._copies:
+                g.record_stream(cur)                        # allocated on the side stream, read here
             dst, src = by_dtype.setdefault(g.dtype, ([], []))
             dst.append(view)
             src.append(g)
