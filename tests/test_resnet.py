@@ -134,3 +134,29 @@ def test_direct_gradients_match_preassigned_views(monkeypatch):
     for a, b in zip(ld[:4], lv[:4]):
         assert abs(a - b) < 0.03, (ld, lv)
     assert ld[-1] < ld[0] and lv[-1] < lv[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw", [(16, 32, 1, 1, 0, 14), (16, 16, 3, 2, 1, 15), (3, 16, 7, 2, 3, 32), (32, 8, 3, 1, 1, 9)])
+def test_convolution_with_weight_gradient_on_a_second_stream(cin, cout, k, stride, pad, hw):
+    """``_ConvWgradAside``: output, data gradient and (after joining the side stream) weight gradient of the
+    convolution are those of F.conv2d; fp32 here, so that the comparison is tight."""
+    from distributed_tensorflow_amd.models.resnet import _ConvWgradAside
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(cin * 7 + k)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False).to(dev)
+    x = torch.randn(4, cin, hw, hw, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = conv.weight.detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    side = torch.cuda.Stream(dev)
+    y = _ConvWgradAside.apply(x, w, conv, side)
+    dy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(dy)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    xr = x.detach().clone().requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, None, stride, pad)
+    yr.backward(dy)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y, yr, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(x.grad, xr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(w.grad, wr.grad, rtol=1e-3, atol=1e-3)
