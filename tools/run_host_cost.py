@@ -92,3 +92,45 @@ for k in (0, 1, 2, 3, 4):
         ts.append((time.perf_counter() - t0) * 1e6)
     ts.sort()
     print("first %d steps direct + graph of %d: total %.1f us (median of 200), min %.1f" % (k, N - k, ts[100], ts[0]))
+
+# experiment: the same graph launched through hipGraphLaunch directly (no torch bookkeeping around it), and after a
+# hipGraphUpload
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipGraphLaunch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+hip.hipGraphLaunch.restype = ctypes.c_int
+hip.hipGraphUpload.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+hip.hipGraphUpload.restype = ctypes.c_int
+stream = torch.cuda.current_stream().cuda_stream
+for label, upload in (("torch replay", None), ("hipGraphLaunch", False), ("hipGraphUpload once + hipGraphLaunch", True)):
+    keys = {}
+    def one():
+        prog._pipe_open()
+        prog.data.prepare(prog.steps_enqueued, N + 3, 100)
+        g = prog._graph_for(N, last=True)
+        if upload is None:
+            g.replay()
+        else:
+            ex = g.raw_cuda_graph_exec()
+            if upload and ex not in keys:
+                keys[ex] = hip.hipGraphUpload(ex, stream)
+            rc = hip.hipGraphLaunch(ex, stream)
+            assert rc == 0, rc
+        prog.steps_enqueued += N
+        prog._pipe_close(launched=True)
+    for _ in range(8):
+        one()
+        torch.cuda.synchronize()
+    ts, hs = [], []
+    for _ in range(200):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e6)
+        hs.append((t1 - t0) * 1e6)
+    ts.sort(), hs.sort()
+    print("%-40s total %.1f us, host %.1f us (medians of 200)%s" % (label, ts[100], hs[100], "  upload rc %s" % set(keys.values()) if keys else ""))
+st_check = prog.read_log(prog.steps_enqueued - 1, 1)[0]
+print("last record after the experiment: local step %d global step %d loss %.4f" % (st_check.local_step, st_check.global_step, st_check.loss))
