@@ -150,6 +150,7 @@ class MLPProgram:
         self._eval_buf: Dict = {}
         self._args = [self._build_args(q) for q in range(self.P)] if self.is_cuda else None
         self._started = False
+        self._log_stream = None                 # stream of log reads that must not wait for later launches
         self.pipe_primes = 0                    # prime launches so far (diagnostic)
         self._pipe_live = None                  # _pipe_token() of the state the pipeline's working copies continue from
         # Called at the end of every step, inside the captured region: the engine's gradient
@@ -586,13 +587,16 @@ class MLPProgram:
         if self.pipe:
             self._pipe_close(launched=flushed)
 
-    def read_log(self, first_local_step: int, count: int) -> List[StepRecord]:
-        """Records of local steps ``[first, first+count)`` (0-based).  Synchronises with the device."""
+    def read_log(self, first_local_step: int, count: int, after=None) -> List[StepRecord]:
+        """Records of local steps ``[first, first+count)`` (0-based).  Synchronises with the device; with ``after`` (an
+        event recorded behind the launch that ran those steps) only with that event: the records cross the host link
+        on a stream of their own while later launches keep the device busy."""
         if count > self.log_cap:
             raise ValueError("asked for more records than the log ring holds")
-        log = self._log_host(first_local_step, count).numpy()
+        log = self._log_host(first_local_step, count, after).numpy()
         loss = log[:, 0].copy().view("<f4").tolist()
         correct, post, gs = log[:, 1].tolist(), log[:, 2].tolist(), log[:, 3].tolist()
+        self.first_post_of_last_read = post[0]       # accuracy-only rows of the first step read (= the step before it)
         out = [StepRecord(local_step=first_local_step + i + 1, global_step=gs[i], loss=loss[i], train_correct=correct[i],
                           batch=self.B) for i in range(count)]
         if self.post:
@@ -601,20 +605,28 @@ class MLPProgram:
                 out[i].post_correct = post[i + 1]
         return out
 
-    def _log_host(self, first_local_step: int = 0, count: Optional[int] = None) -> torch.Tensor:
+    def _log_host(self, first_local_step: int = 0, count: Optional[int] = None, after=None) -> torch.Tensor:
         """Records of local steps ``[first, first + count)`` (default: the whole ring, indexed by step % capacity) on
         the host as ``[count, 4]`` int32 {loss bits, correct, post, global_step}.  The two-launch and the one-launch
         step log per-row-block partial sums; they are folded here in a fixed order.  Only the rows asked for cross
         the host link."""
         src = self.wlog if (self.fused2 or self.pipe) else self.log
-        if count is None:
-            w = src.cpu()
-        else:
+
+        def fetch():
+            if count is None:
+                return src.cpu()
             lo = first_local_step % self.log_cap
             if lo + count <= self.log_cap:
-                w = src[lo:lo + count].cpu()
-            else:                                       # the range wraps around the ring
-                w = torch.cat([src[lo:], src[:lo + count - self.log_cap]]).cpu()
+                return src[lo:lo + count].cpu()
+            return torch.cat([src[lo:], src[:lo + count - self.log_cap]]).cpu()     # the range wraps around the ring
+        if after is not None and self.is_cuda:
+            if self._log_stream is None:
+                self._log_stream = torch.cuda.Stream(self.device)
+            with torch.cuda.stream(self._log_stream):
+                self._log_stream.wait_event(after)
+                w = fetch()                             # waits for this stream only
+        else:
+            w = fetch()
         if not (self.fused2 or self.pipe):
             return w
         nb = (self.R + 15) // 16

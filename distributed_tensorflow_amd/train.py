@@ -121,8 +121,9 @@ class TrainingLoop:
         self.validation_accuracies.append(acc)
         self.emit('Worker %d: validation accuracy %g' % (self.task, acc))
 
-    def _plan(self, last_seen_gs: int) -> int:
-        to_validation = self.validation_every - (self.local_step % self.validation_every)
+    def _plan(self, last_seen_gs: int, local_step: Optional[int] = None) -> int:
+        local_step = self.local_step if local_step is None else local_step
+        to_validation = self.validation_every - (local_step % self.validation_every)
         if self.is_async:
             # other workers advance global_step too: approach the limit in shrinking launches
             remaining = max(1, (self.train_steps - last_seen_gs + 1) // max(1, self.world))
@@ -134,7 +135,87 @@ class TrainingLoop:
         # cap and to_validation count local steps, `remaining` counts updates
         return max(1, min(cap // self.rounds, remaining, to_validation // self.rounds))
 
+    def _can_overlap(self) -> bool:
+        """Launch ahead of the log processing?  Only where the launches do not depend on what the log says: sync mode
+        with every update made of one step per worker, or one worker alone in async mode (global_step then advances
+        by exactly one per step), on a GPU, with nothing that may end the training from outside.  One worker by default (measured: 200 000 steps with
+        every step printed 2.04 -> 1.39 s); DTF_LOOP_OVERLAP=2 also with several workers, whose engines synchronise
+        with the host inside every run anyway."""
+        import os
+        mode = os.environ.get("DTF_LOOP_OVERLAP", "1")
+        return (mode != "0" and (self.world == 1 or (mode == "2" and not self.is_async)) and self.stop_check is None
+                and self.rounds == 1 and isinstance(self.prog, MLPProgram) and self.prog.is_cuda)
+
+    def _run_overlapped(self) -> float:
+        """``run`` with up to two launches in flight: while the host decodes and prints the records of one launch, the
+        device runs the next.  Records are read on a stream of their own behind an event recorded after their launch.
+        Order and content of everything printed are those of the plain loop; launches stop at validation boundaries
+        and at the last update, where the loop drains."""
+        import collections
+        prog = self.prog
+        time_begin = time.time()
+        held: Optional[StepRecord] = None
+        gs_seen = prog.state.global_step()
+        planned_gs, planned_local = gs_seen, self.local_step
+        validated_at = -1
+        inflight = collections.deque()           # (first local step, steps, event behind the launch, global_step before it)
+        done = False
+        launched_any = False                     # the reference checks the stop rule after a step: at least one runs
+        while not done:
+            while len(inflight) < 2 and (planned_gs <= self.train_steps or not launched_any):
+                if planned_local % self.validation_every == 0 and validated_at != planned_local:
+                    break                        # validation first: it reads the parameters of exactly this step
+                n = self._plan(planned_gs, planned_local)
+                with trace.annotate(f"launch {n} updates"):
+                    self.engine.run(n, min(n, 64) if n >= 2 else 1)
+                ev = torch.cuda.Event()
+                ev.record()
+                inflight.append((planned_local, n, ev, planned_gs))
+                launched_any = True
+                planned_local += n
+                planned_gs += n
+            if not inflight:
+                if planned_gs > self.train_steps and launched_any:
+                    break
+                if held is not None:             # keep the reference's line order: step line, then validation
+                    held.post_correct = prog.post_correct_of_last_step()
+                    self._print_record(held)
+                    held = None
+                with trace.annotate("validation"):
+                    self._validate()
+                validated_at = planned_local
+                continue
+            first, n, ev, gs_launch = inflight.popleft()
+            self.local_step = first + n
+            with trace.annotate("read step log"):
+                recs = prog.read_log(first, n, after=ev)
+            if held is not None:
+                held.post_correct = prog.first_post_of_last_read
+                self._print_record(held)
+                held = None
+            for r in recs:
+                stop_here = r.global_step >= self.train_steps
+                if prog.post and r.post_correct is None:          # only the last record of a launch
+                    if not stop_here:
+                        held = r                 # resolved by the next launch's first step, or in front of a validation
+                        break
+                    r.post_correct = prog.post_correct_of_last_step()
+                self._print_record(r)
+                if stop_here:
+                    done = True
+                    break
+            gs_seen = recs[-1].global_step + 1
+            planned_gs += gs_seen - (gs_launch + n)               # (zero unless something else moved global_step)
+            if self.sv is not None:
+                with trace.annotate("checkpoint check"):
+                    self.sv.maybe_checkpoint()
+                self.sv.report_step_rate(gs_seen)
+        time_end = time.time()
+        return time_end - time_begin
+
     def run(self) -> float:
+        if self._can_overlap():
+            return self._run_overlapped()
         prog = self.prog
         time_begin = time.time()
         held: Optional[StepRecord] = None        # last record of the previous launch, waiting for its post-update accuracy
