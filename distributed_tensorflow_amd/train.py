@@ -143,8 +143,9 @@ class TrainingLoop:
         with the host inside every run anyway."""
         import os
         mode = os.environ.get("DTF_LOOP_OVERLAP", "1")
+        # ("cpu": the same control flow without a device to overlap with, for tests that have no GPU)
         return (mode != "0" and (self.world == 1 or (mode == "2" and not self.is_async)) and self.stop_check is None
-                and self.rounds == 1 and isinstance(self.prog, MLPProgram) and self.prog.is_cuda)
+                and self.rounds == 1 and isinstance(self.prog, MLPProgram) and (self.prog.is_cuda or mode == "cpu"))
 
     def _run_overlapped(self) -> float:
         """``run`` with up to two launches in flight: while the host decodes and prints the records of one launch, the
@@ -168,8 +169,10 @@ class TrainingLoop:
                 n = self._plan(planned_gs, planned_local)
                 with trace.annotate(f"launch {n} updates"):
                     self.engine.run(n, min(n, 64) if n >= 2 else 1)
-                ev = torch.cuda.Event()
-                ev.record()
+                ev = None
+                if prog.is_cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
                 inflight.append((planned_local, n, ev, planned_gs))
                 launched_any = True
                 planned_local += n

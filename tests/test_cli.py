@@ -129,3 +129,23 @@ def test_two_workers_sync_r3_runs_exactly_train_steps_updates():
     t0 = [l for l in l0 if "test accuracy" in l][0].split()[-1]
     t1 = [l for l in l1 if "test accuracy" in l][0].split()[-1]
     assert t0 == t1
+
+
+@pytest.mark.parametrize("extra,steps", [(["--sync_replicas", "--validation_every=10"], 47), (["--validation_every=7", "--steps_per_launch=5"], 30),
+                                         (["--sync_replicas", "--validation_every=1000", "--nopost_update_accuracy"], 33)])
+def test_loop_that_launches_ahead_prints_what_the_plain_loop_prints(extra, steps):
+    """The control flow of the GPU loop that keeps two launches in flight (train.TrainingLoop._run_overlapped), run on
+    the CPU: every line it prints is the plain loop's."""
+    args = ["--single_process", "--train_steps=%d" % steps, "--synthetic_data", "--synthetic_train_size=2000", "--device=cpu",
+            "--learning_rate=0.5", "--seed=7"] + extra
+
+    def run(mode):
+        env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONUNBUFFERED="1", DTF_LOOP_OVERLAP=mode)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "distributed.py")] + args, capture_output=True, text=True,
+                           env=env, cwd=ROOT, timeout=300)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return [l for l in p.stdout.splitlines() if not l.startswith("Training elapsed time") and "examples/sec" not in l]
+
+    plain, ahead = run("0"), run("cpu")
+    assert plain == ahead
+    assert [s[0] for s in _steps(ahead)] == list(range(1, steps + 1))
