@@ -35,3 +35,32 @@ def test_overlapped_loop_prints_what_the_plain_loop_prints(extra, steps):
     assert [r[1] for r in recs] == list(range(1, steps + 1))          # global_step starts at 1; the last fetched value is train_steps
     assert recs[-1][2] < recs[0][2]
     assert any(l.startswith("Worker 0: test accuracy") for l in ahead)
+
+
+def test_two_sync_workers_sharing_the_gpu_print_the_same_with_both_loops():
+    """1 ps + 2 workers as processes of the script, the workers on the one GPU of the box (gloo process group, peer-mapped
+    sync step): the loop that launches ahead prints what the plain loop prints, on both workers."""
+    from dist_utils import free_port
+
+    def run(mode):
+        ports = [free_port() for _ in range(3)]
+        common = ["--ps_hosts=127.0.0.1:%d" % ports[2], "--worker_hosts=127.0.0.1:%d,127.0.0.1:%d" % (ports[0], ports[1]),
+                  "--sync_replicas", "--train_steps=1200", "--synthetic_data", "--synthetic_train_size=4000", "--learning_rate=0.5",
+                  "--seed=7", "--validation_every=500", "--log_every=25", "--dist_backend=gloo"]
+        env = dict(os.environ, PYTHONUNBUFFERED="1", DTF_LOOP_OVERLAP=mode, DTF_SHARE_GPU="1", DTF_P2P_ALLREDUCE="1")
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "distributed.py"), "--job_name=%s" % job, "--task_index=%d" % idx]
+                                  + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+                 for job, idx in (("ps", 0), ("worker", 1), ("worker", 0))]
+        outs = []
+        for p in procs:
+            out, err = p.communicate(timeout=300)
+            assert p.returncode == 0, err[-3000:]
+            outs.append([l for l in out.splitlines() if not l.startswith("Training elapsed time") and "examples/sec" not in l])
+        return outs[1], outs[2]
+
+    (w1_plain, w0_plain), (w1_ahead, w0_ahead) = run("0"), run("1")
+    assert w0_plain == w0_ahead and w1_plain == w1_ahead
+    steps = [STEP_RE.match(l) for l in w0_ahead]
+    steps = [(int(m.group(1)), int(m.group(2))) for m in steps if m]
+    assert steps and steps[-1][1] <= 1200 and all(a[0] < b[0] for a, b in zip(steps, steps[1:]))
+    assert any(l.startswith("Worker 0: test accuracy") for l in w0_ahead)
