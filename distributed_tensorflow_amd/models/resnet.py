@@ -106,7 +106,12 @@ class _ConvWgradAside(torch.autograd.Function):
     gradient of the convolution); the weight gradient is needed only when the optimizer runs.  Its kernels (and the
     library's zero-fill / cast helpers around them) go to a side stream, where they run beside the bandwidth-bound
     batch-norm kernels of the main chain and fill the gaps between its dependent launches.  The owner of the side
-    stream joins it before it reads the gradients (``TorchModuleProgram._gradients_to_flat``)."""
+    stream joins it before it reads the gradients (``TorchModuleProgram._gradients_to_flat``).
+
+    The weight gradient is NOT returned to autograd: the engine believes a node's outputs were produced on the stream
+    the node ran on, and where it copies a returned gradient (strides that differ from the leaf's, a hook, a second
+    reference) that copy would be a main-stream kernel racing the side-stream producer.  The gradient is stored into
+    ``w.grad`` here, on the side stream, and autograd gets None for ``w``."""
 
     @staticmethod
     def forward(ctx, x, w, conv, side):
@@ -127,12 +132,16 @@ class _ConvWgradAside(torch.autograd.Function):
             side.wait_stream(main)                          # gy exists from here on
             with torch.cuda.stream(side):
                 gw = torch.ops.aten.convolution_backward(gy, x, w, *args, [False, True, False])[1]
+                if w.grad is None:
+                    w.grad = gw
+                else:
+                    w.grad.add_(gw)                         # a weight used by several convolutions of one step
             # their memory must not be handed out again on the main stream while the side stream still reads it
             gy.record_stream(side)
             x.record_stream(side)
         if ctx.needs_input_grad[0]:
             gx = torch.ops.aten.convolution_backward(gy, x, w, *args, [True, False, False])[0]
-        return gx, gw, None, None
+        return gx, None, None, None
 
 
 class TorchModuleProgram:
@@ -169,6 +178,7 @@ class TorchModuleProgram:
         # hook fires: that path keeps the preassigned views.  DTF_DIRECT_GRADS=0 selects it everywhere.
         self.direct_grads = self.device.type == "cuda" and os.environ.get("DTF_DIRECT_GRADS", "1") != "0"
         self._direct_now = False
+        self._in_step = False                   # True while _step_body runs its forward and backward pass
         self._params = [p for _, p in named]
         self._grad_views = [self.state.grad(n) for n, _ in named]
         self._copies = {}                       # id(master parameter) -> compute-precision leaf the convolution reads
@@ -221,8 +231,10 @@ class TorchModuleProgram:
 
     def _conv_forward(self, m: nn.Conv2d, w: torch.Tensor):
         def forward(x):
-            if self._direct_now:
-                if self._side is not None and torch.is_grad_enabled():
+            # the compute copies are refreshed at the start of a training step only: any other forward pass
+            # (evaluation, a pass after load_values or a restore) reads the master weights
+            if self._direct_now and self.module.training and torch.is_grad_enabled() and self._in_step:
+                if self._side is not None:
                     return _ConvWgradAside.apply(x, w, m, self._side)
                 return m._conv_forward(x, w, None)
             return nn.Conv2d.forward(m, x)
@@ -312,6 +324,20 @@ class TorchModuleProgram:
             self.state.grads.zero_()
         if self._bn_counters:
             torch._foreach_add_(self._bn_counters, 1)
+        self._in_step = True
+        try:
+            self._forward_backward(x, y)
+        finally:
+            self._in_step = False
+        if direct:
+            self._gradients_to_flat()
+        self._last_gs.copy_(self.state.state[0:1])
+        if self.after_compute is not None:
+            self.after_compute()
+        self.state.state[0:1].add_(self.gs_inc)
+        self.state.state[1:2].add_(1)
+
+    def _forward_backward(self, x, y) -> None:
         if self.fused_head:
             # classifier + loss + accuracy count: one autograd node on the framework's own kernels
             with torch.autocast(self.device.type, dtype=self.autocast, enabled=self.autocast is not None):
@@ -327,13 +353,6 @@ class TorchModuleProgram:
             loss.backward()
             self._last[0:1].copy_(loss.detach().reshape(1))
             self._last[1:2].copy_((logits.argmax(1) == y).sum().float().reshape(1))
-        if direct:
-            self._gradients_to_flat()
-        self._last_gs.copy_(self.state.state[0:1])
-        if self.after_compute is not None:
-            self.after_compute()
-        self.state.state[0:1].add_(self.gs_inc)
-        self.state.state[1:2].add_(1)
 
     def _capture(self) -> None:
         """Capture ``_step_body`` on static input buffers.  Called after eager steps have run (MIOpen has chosen its

@@ -121,6 +121,7 @@ class PeerMappedAsyncEngine:
         self.updates_pushed = 0
         self.last_global_step = 1
         self._applied_final: Optional[int] = None
+        self._finished = False
         self._local = None
         self._mapped: List[int] = []
         lib = _lib_k()
@@ -234,6 +235,10 @@ class PeerMappedAsyncEngine:
         part, so the chief can checkpoint while everybody keeps training), or None for SGD."""
         if not self.adam:
             return None
+        if self._finished:
+            # finish() has unmapped the peers' regions (reading them now would fault the GPU); what this rank owned
+            # came home into state.m / state.v there, the other owners' slices are out of reach
+            raise RuntimeError("gather_moments after finish(): take the final checkpoint before the engine is torn down")
         n = self.state.layout.total
         full_m = torch.empty(n, dtype=torch.float32, device=self.device)
         full_v = torch.empty(n, dtype=torch.float32, device=self.device)
@@ -360,6 +365,7 @@ class PeerMappedAsyncEngine:
                 self.state.m.copy_(mv[0])                # the slot variables come home for the final checkpoint
                 self.state.v.copy_(mv[1])
                 self.state.state[2] = self._applied_final
+        self._finished = True
         self._release(free_local=everyone)
         return everyone
 

@@ -103,6 +103,7 @@ class AsyncParameterServerEngine:
         # Adam: the owner keeps the moments of its slice and counts the updates it applied (bias correction)
         self._m = self._v = None
         self._adam_t = 0
+        self._finished = False
         if state.optimizer == "adam" and self.is_owner:
             self._m = torch.zeros(self.slice, dtype=f32, device=self.device)
             self._v = torch.zeros(self.slice, dtype=f32, device=self.device)
@@ -166,9 +167,13 @@ class AsyncParameterServerEngine:
             if kind == KIND_DONE:
                 return
             if kind == KIND_MOMENTS:
-                for t in (self._m, self._v):
+                # m, v and the update count of ONE update: snapshot under the lock the Adam applications hold
+                with self._gs_lock:
+                    snap = [t.clone() if t is not None else None for t in (self._m, self._v)]
+                    count = self._adam_t
+                for t in snap:
                     out[:self.slice].copy_(t) if t is not None else out[:self.slice].zero_()
-                    self._ints(out)[0] = self._adam_t
+                    self._ints(out)[0] = count
                     dist.send(out, dst=w, group=group)
                 continue
             gs = None
@@ -288,6 +293,9 @@ class AsyncParameterServerEngine:
         st = self.state
         if st.optimizer != "adam":
             return None
+        if self._finished:
+            # the owners' service threads have returned: a request for their moments would never be answered
+            raise RuntimeError("gather_moments after finish(): take the final checkpoint before the engine is torn down")
         while self._pending:
             self._complete_oldest()
         n = st.layout.total
@@ -296,9 +304,10 @@ class AsyncParameterServerEngine:
         for s in range(self.S):
             lo, hi = self._shard_range(s)
             if s == self.rank:
-                full[0][lo:hi].copy_(self._m)
-                full[1][lo:hi].copy_(self._v)
-                st.state[2] = self._adam_t
+                with self._gs_lock:
+                    full[0][lo:hi].copy_(self._m)
+                    full[1][lo:hi].copy_(self._v)
+                    st.state[2] = self._adam_t
                 continue
             dist.send(torch.tensor([KIND_MOMENTS, 0], dtype=torch.int64), dst=s, group=self.groups[(s, self.rank, "ctl")])
             for k in range(2):
@@ -315,6 +324,7 @@ class AsyncParameterServerEngine:
         import time
         while self._pending:
             self._complete_oldest()
+        self._finished = True
         if self.world > 1:
             self._exchange(KIND_DONE)
         deadline = time.time() + timeout_s

@@ -166,7 +166,8 @@ class TrainingLoop:
             while len(inflight) < 2 and (planned_gs <= self.train_steps or not launched_any):
                 if planned_local % self.validation_every == 0 and validated_at != planned_local:
                     break                        # validation first: it reads the parameters of exactly this step
-                n = self._plan(planned_gs, planned_local)
+                # two launches share the log ring: the one being read and the one running must both fit
+                n = min(self._plan(planned_gs, planned_local), max(1, (prog.log_cap - 1) // 2))
                 with trace.annotate(f"launch {n} updates"):
                     self.engine.run(n, min(n, 64) if n >= 2 else 1)
                 ev = None
@@ -208,7 +209,11 @@ class TrainingLoop:
                     done = True
                     break
             gs_seen = recs[-1].global_step + 1
-            planned_gs += gs_seen - (gs_launch + n)               # (zero unless something else moved global_step)
+            delta = gs_seen - (gs_launch + n)                     # (zero unless something else moved global_step)
+            if delta:
+                planned_gs += delta
+                # the launch still in flight was planned with the uncorrected value: correct it once, here
+                inflight = collections.deque((f, k, e, g + delta) for f, k, e, g in inflight)
             if self.sv is not None:
                 with trace.annotate("checkpoint check"):
                     self.sv.maybe_checkpoint()
@@ -395,9 +400,11 @@ def main(unused_argv=None) -> int:
     examples = loop.local_step * FLAGS.batch_size
     print('Worker %d: %d local steps, %.1f examples/sec on this worker' % (FLAGS.task_index, loop.local_step,
                                                                            examples / max(train_time, 1e-9)))
+    # The final checkpoint comes BEFORE the engine is torn down: with Adam the chief reads the slot variables from the
+    # owners (mapped regions / their service threads), which finish() releases / lets return.
+    sv.stop()
     if is_async:
         engine.finish()
-    sv.stop()
     server.shutdown()
     sys.stdout.flush()
     return 0

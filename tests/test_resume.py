@@ -148,3 +148,47 @@ def test_async_send_recv_engine_resumes_counters_and_moments(tmp_path):
     got = pyformat.read_bundle(latest_checkpoint(str(tmp_path)))
     assert int(got["global_step"]) == 41
     assert np.abs(got["hid_w/Adam"]).sum() > 0 and np.abs(got["sm_w/Adam_1"]).sum() > 0     # both owners' slices arrived
+
+
+def _async_cli_order_rank(rank, world, port, logdir):
+    """The order of the training script's last lines: every worker on its own does run -> sync_params -> final
+    checkpoint (chief) -> finish; no barrier in between, so the chief asks for the other owner's moments while that
+    worker may already sit in finish()."""
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterServerEngine
+    from distributed_tensorflow_amd.supervisor.supervisor import Supervisor
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    store = dist.distributed_c10d._get_default_store()
+    ds = mnist.synthetic_data_sets(train_size=700, validation_size=50, test_size=50, seed=40 + rank)
+    st = build_mlp_state(784, [32], 10, "cpu", world_size=world, rank=rank, optimizer="adam", lr=0.01)
+    sv = Supervisor(rank == 0, logdir, lambda: st.initialize(9), st, recovery_wait_secs=0.05, save_model_secs=600,
+                    store=store, group_size=world)
+    sv.prepare_or_wait_for_session()
+    prog = MLPProgram(st, DeviceDataset(ds.train, "cpu", shuffle_seed=40 + rank), 50, [32], fused_update=False, gs_inc=0,
+                      post_update_accuracy=False)
+    eng = AsyncParameterServerEngine(prog, st, num_shards=2, staleness=0)
+    sv.engine = eng
+    eng.publish_state()
+    eng.run(6 if rank == 0 else 3)                    # the chief is the last to finish training
+    eng.sync_params()
+    sv.stop()
+    everyone = eng.finish(timeout_s=60)
+    refused = False
+    try:
+        eng.gather_moments()
+    except RuntimeError:
+        refused = True
+    dist.barrier()
+    dist.destroy_process_group()
+    return {"everyone": everyone, "refused": refused}
+
+
+@pytest.mark.slow
+def test_async_final_checkpoint_in_the_training_scripts_order(tmp_path):
+    res = run_ranks(_async_cli_order_rank, 2, str(tmp_path), timeout=200)
+    assert all(r["everyone"] and r["refused"] for r in res)
+    got = pyformat.read_bundle(latest_checkpoint(str(tmp_path)))
+    # both owners' slot variables are in the final checkpoint (sm_w lies in the second shard)
+    assert np.abs(got["hid_w/Adam"]).sum() > 0 and np.abs(got["sm_w/Adam_1"]).sum() > 0
