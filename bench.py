@@ -9,7 +9,8 @@ trained synchronously with the parameter-server state sharded across the GPUs.
         --master-port P bench.py --gpus N --steps K --warmup W  # the same under an external launcher
 
 This mirrors the reference's launch recipe (one process per worker GPU, /root/reference/README.md:7-15):
-with ``--gpus N`` and no ``WORLD_SIZE`` in the environment this process never touches a GPU; it starts N
+with ``--gpus N`` and no ``WORLD_SIZE`` in the environment this process never touches a GPU (it counts them in the
+kernel driver's sysfs topology, without the HIP runtime); it starts N
 fresh worker processes (``LOCAL_RANK`` = GPU index, a free rendezvous port on 127.0.0.1), forwards their
 stderr, prints rank 0's ONE JSON line and exits non-zero if any worker does.
 
@@ -59,6 +60,14 @@ def parse_args(argv=None):
                          "kernel of the run (measured slower and noisier in a fresh process; kept for comparison)")
     ap.add_argument("--no_second_mode", action="store_true",
                     help="N>1, mlp_sync: skip the extra timed segment in the other update mode (async_value)")
+    ap.add_argument("--target_loss", type=float, default=2.0,
+                    help="reference MLP: after the timed segment, train a fresh state until the trailing-10 mean of the "
+                         "training loss is at or below this on every worker and report steps_to_target (the double-softmax "
+                         "loss lives in (1.46, 2.30); 0 skips the segment)")
+    ap.add_argument("--target_max_steps", type=int, default=4096, help="give up the steps-to-target segment after this many local steps")
+    ap.add_argument("--staleness_bound", type=int, default=None,
+                    help="async configs: a worker whose replica misses more than this many updates of the job pulls before it "
+                         "computes (default: staleness + 2 x (workers - 1); negative: no bound)")
     ap.add_argument("--cpu", action="store_true", help="run on CPU with gloo (functional check only)")
     ap.add_argument("--force_collectives", action="store_true",
                     help="N=1 only: run the multi-rank code path (gradient store, RCCL collective on a one-rank "
@@ -79,6 +88,37 @@ def _pump(stream, sink, prefix: str) -> None:
     stream.close()
 
 
+def count_gpus_without_hip():
+    """GPUs this process's children will see, found without loading the HIP runtime or opening the GPU device node:
+    the kernel driver's topology in sysfs lists every agent, and the GPU agents are the nodes with SIMDs.  A
+    visibility list in the environment (what the reference's recipe sets per worker, /root/reference/README.md:7-15)
+    narrows the count.  None when the topology cannot be read (then the workers find out themselves)."""
+    import glob
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                                                  # no compute driver loaded: no GPU
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    gpus = 0
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(line.split(None, 1) for line in f if len(line.split(None, 1)) == 2)
+        except OSError:
+            return None
+        try:
+            if int(props.get("simd_count", "0")) > 0:
+                gpus += 1
+        except ValueError:
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = [t for t in v.split(",") if t.strip() != ""]
+            gpus = min(gpus, len(listed))
+    return gpus
+
+
 def launch_workers(args, argv) -> int:
     """Start one worker process per GPU and relay rank 0's JSON line.  The parent makes no HIP call: the
     children are fresh interpreters created before anything here could have initialised a GPU."""
@@ -87,8 +127,9 @@ def launch_workers(args, argv) -> int:
     env_base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL and the peer-mapped buffers need it
     env_base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
     if not args.cpu:
-        import torch                                              # device_count() does not initialise the GPU
-        have = torch.cuda.device_count()
+        have = count_gpus_without_hip()
+        if have is None:
+            have = n                                              # unknown here: a worker without a GPU says so itself
         if have == 0:
             sys.stderr.write("[bench] no GPU visible: add --cpu for the gloo rehearsal\n")
             return 2

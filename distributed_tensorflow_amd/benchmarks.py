@@ -91,6 +91,72 @@ def _rccl_probe(engine, rank, world, device):
         return None
 
 
+def _assert_rccl_world(engine, rank, world, device):
+    """N > 1 on RCCL: the communicator must really span N ranks - its own count and an all-reduce of ones both say N -
+    or the run fails loudly (a degenerate communicator would otherwise time N independent one-rank jobs and report
+    their sum as a scaling result).  Returns the probe record for the result line (None off RCCL)."""
+    if world <= 1 or device.type != "cuda" or not dist.is_initialized() or dist.get_backend() != "nccl":
+        return None
+    probe = _rccl_probe(engine, rank, world, device)
+    if probe is None:
+        # no native communicator in this build / disabled: the same two facts through torch.distributed (also RCCL)
+        ones = torch.ones(4, dtype=torch.float32, device=device)
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        probe = {"rccl_ranks": dist.get_world_size(), "rccl_allreduce_of_ones": float(ones[0].item())}
+    if probe["rccl_ranks"] != world or probe["rccl_allreduce_of_ones"] != float(world):
+        raise SystemExit(f"[bench] rank {rank}: the RCCL communicator does not span the job: {probe} with --gpus {world}")
+    return probe
+
+
+def _steps_to_target(engine, prog, state, batch, per_update, args, rank, world, device, is_async=False):
+    """Second half of the headline metric: global steps (aggregated updates in sync mode, all workers' updates in
+    async mode, /root/reference/distributed.py:155) until the trailing-10 mean of the training loss that the loop
+    prints every step (:152-153) is at or below ``--target_loss`` on EVERY worker.  ``engine`` / ``prog`` / ``state``
+    are fresh (same seed as the timed job, nothing trained yet); runs after the timed segment, outside every clock."""
+    target, limit, chunk = float(args.target_loss), int(args.target_max_steps), 16
+    cpu_flags = world > 1 and dist.get_backend() != "nccl"
+    losses, local_steps, hit = [], 0, None
+    first = prog.steps_enqueued
+    while local_steps < limit:
+        engine.run(chunk, chunk)
+        recs = prog.read_log(first + local_steps, chunk)
+        local_steps += chunk
+        losses += [r.loss for r in recs]
+        # first step at which the trailing-10 mean was at or below the target, on this worker
+        mine = None
+        for i in range(max(10, local_steps - chunk), local_steps + 1):
+            if i >= 10 and sum(losses[i - 10:i]) / 10.0 <= target:
+                mine = i
+                break
+        above = 0 if mine is not None else 1
+        if world > 1:
+            t = torch.tensor([above], dtype=torch.int32, device="cpu" if cpu_flags else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)        # stop together, when every worker is below the target
+            above = int(t.item())
+        if not above:
+            hit = mine
+            if world > 1:                                    # the slowest worker's step speaks for the job
+                t = torch.tensor([hit if hit is not None else local_steps], dtype=torch.int32,
+                                 device="cpu" if cpu_flags else device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                hit = int(t.item())
+            break
+    if is_async and world > 1:
+        engine.sync_params()
+    out = {"target_loss": target, "lr": state.lr, "reached": hit is not None,
+           "local_steps_per_worker": hit if hit is not None else local_steps,
+           "loss_at_stop": sum(losses[-10:]) / max(1, min(10, len(losses)))}
+    if hit is not None:
+        # sync: one global step per aggregated update = per local step of every worker; async: every worker's
+        # local step is an update
+        out["steps_to_target"] = hit * (world if is_async else 1)
+        out["examples_to_target"] = hit * batch * (world if is_async else per_update)
+    else:
+        out["steps_to_target"] = out["examples_to_target"] = None
+    return out
+
+
 def _time_segment(engine, device, world, steps, graph_steps):
     _sync_all(device, world)
     t0 = time.perf_counter()
@@ -220,21 +286,34 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     last = prog.read_log(prog.steps_enqueued - 1, 1)[0]
     # examples per aggregated update: R gradients of `batch` examples each (distributed.py:92-100)
     value = batch * args.steps * R / dt
-    probe = _rccl_probe(engine, rank, world, device) if world > 1 else None
+    probe = _assert_rccl_world(engine, rank, world, device)
+    target = None
+    if not wide and fast and getattr(args, "target_loss", 0):
+        # steps to the target loss from a fresh state (same seed), same engine settings, outside every clock
+        if engine.p2p is not None:
+            torch.cuda.synchronize()
+            engine.p2p.close()
+        state_t, prog_t, engine_t = build()
+        if selection is not None and engine_t.p2p is not None:
+            engine_t.set_p2p_mode(selection["chosen"])
+        target = _steps_to_target(engine_t, prog_t, state_t, batch, R, args, rank, world, device)
+        if engine_t.p2p is not None:
+            torch.cuda.synchronize()
+            engine_t.p2p.close()
     second = None
     if world > 1 and not wide and fast and not getattr(args, "no_second_mode", False):
         # the other update mode of the same job, timed the same way, so that one invocation yields both numbers
         transport = engine.transport
         dropped = engine.dropped
-        if engine.p2p is not None:
+        if engine.p2p is not None and target is None:
             torch.cuda.synchronize()
             engine.p2p.close()
         a2 = _async_args(args)
         second = bench_mlp_async(a2, rank, world, device)
         return _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer, dtype_name, R, dt, state, prog,
-                            engine, force, last, selection, probe, second, transport, dropped)
+                            engine, force, last, selection, probe, second, transport, dropped, target)
     return _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer, dtype_name, R, dt, state, prog, engine,
-                        force, last, selection, probe, second, engine.transport, engine.dropped)
+                        force, last, selection, probe, second, engine.transport, engine.dropped, target)
 
 
 def _async_args(args):
@@ -245,7 +324,7 @@ def _async_args(args):
 
 
 def _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer, dtype_name, R, dt, state, prog, engine, force,
-                 last, selection, probe, second, transport, dropped):
+                 last, selection, probe, second, transport, dropped, target=None):
     value = batch * args.steps * R / dt
     out = {
         "metric": METRIC, "value": value, "unit": "examples/sec", "n_gpus": world, "steps": args.steps,
@@ -280,11 +359,17 @@ def _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer
         out["config"]["transport_selection"] = selection
     if probe is not None:
         out.update(probe)
+    if target is not None:
+        out["target_loss"] = target["target_loss"]
+        out["steps_to_target"] = target["steps_to_target"]
+        out["examples_to_target"] = target["examples_to_target"]
+        out["steps_to_target_detail"] = target
     if second is not None:
         out["async_value"] = second["value"]
         out["async_ms_per_step"] = second["ms_per_step"]
         out["async_config"] = second["config"]
-        for k in ("staleness_max", "staleness_mean", "global_step"):
+        for k in ("staleness_max", "staleness_mean", "global_step", "steps_to_target", "examples_to_target",
+                  "staleness_bound", "forced_pulls"):
             if k in second:
                 out["async_" + k] = second[k]
     return out
@@ -369,38 +454,43 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
     # reference behaviour: every step reads the ps-resident variables (staleness 0); --staleness k pulls every (k+1)-th step
     staleness = args.staleness if getattr(args, "staleness", None) is not None else 0
     ds = mnist.synthetic_data_sets(train_size=train_rows, validation_size=100, test_size=100, seed=rank)
-    state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer=optimizer, lr=lr)
-    state.initialize(seed=1234)
-    data = DeviceDataset(ds.train, device, shuffle_seed=1000 + rank)
-
-    def program(fused, gs_inc):
-        if wide:
-            cdtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
-            args.no_post_update_accuracy = True
-            return WideMLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, dtype=cdtype, gs_inc=gs_inc)
-        return MLPProgram(state, data, batch, hidden, fused_update=fused, gs_inc=gs_inc,
-                          post_update_accuracy=not args.no_post_update_accuracy)
-
     force = bool(getattr(args, "force_collectives", False)) and world == 1 and device.type == "cuda" and not wide
-    if force:
-        # N=1 only: the multi-rank code path (gradients stored, push/pull kernel through the exported region)
-        from .parallel.async_peer import PeerMappedAsyncEngine
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29534")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-        prog = program(fused=False, gs_inc=0)
-        engine = PeerMappedAsyncEngine(prog, state, 1, staleness=staleness)
-        finish = engine.finish
-    elif world == 1:
-        # one worker and its own ps: every update is applied before the next gradient is computed
-        prog = program(fused=optimizer == "sgd", gs_inc=1)
-        engine = SyncReplicasEngine(prog, state)
-        finish = lambda: None
-    else:
-        prog = program(fused=False, gs_inc=0)
-        engine = make_async_engine(prog, state, shards, staleness)
-        finish = engine.finish
+
+    def make():
+        state = build_mlp_state(784, hidden, 10, device, world_size=world, rank=rank, optimizer=optimizer, lr=lr)
+        state.initialize(seed=1234)
+        data = DeviceDataset(ds.train, device, shuffle_seed=1000 + rank)
+
+        def program(fused, gs_inc):
+            if wide:
+                cdtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+                args.no_post_update_accuracy = True
+                return WideMLPProgram(state, data, batch, hidden, loss_mode=ops.LOSS_REFERENCE, dtype=cdtype, gs_inc=gs_inc)
+            return MLPProgram(state, data, batch, hidden, fused_update=fused, gs_inc=gs_inc,
+                              post_update_accuracy=not args.no_post_update_accuracy)
+
+        if force:
+            # N=1 only: the multi-rank code path (gradients stored, push/pull kernel through the exported region)
+            from .parallel.async_peer import PeerMappedAsyncEngine
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29534")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            prog = program(fused=False, gs_inc=0)
+            engine = PeerMappedAsyncEngine(prog, state, 1, staleness=staleness)
+            finish = engine.finish
+        elif world == 1:
+            # one worker and its own ps: every update is applied before the next gradient is computed
+            prog = program(fused=optimizer == "sgd", gs_inc=1)
+            engine = SyncReplicasEngine(prog, state)
+            finish = lambda: None
+        else:
+            prog = program(fused=False, gs_inc=0)
+            engine = make_async_engine(prog, state, shards, staleness)
+            finish = engine.finish
+        return state, prog, engine, finish
+
+    state, prog, engine, finish = make()
     _sync_all(device, world)
     engine.run(args.warmup, 64)
     if type(engine).__name__ in ("PeerMappedAsyncEngine", "SyncReplicasEngine"):    # engines whose steps replay from graphs
@@ -418,7 +508,15 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
         smax = int(_max_over_ranks(float(smax), device, world))
         smean = _max_over_ranks(smean, device, world)
         stale = (smax, smean)
+    forced = None
+    if hasattr(engine, "forced_pulls"):
+        forced = int(_max_over_ranks(float(engine.forced_pulls()), device, world))
     finish()
+    target = None
+    if not wide and getattr(args, "target_loss", 0):
+        state_t, prog_t, engine_t, finish_t = make()
+        target = _steps_to_target(engine_t, prog_t, state_t, batch, 1, args, rank, world, device, is_async=True)
+        finish_t()
     out = {
         "metric": METRIC, "value": batch * args.steps * world / dt, "unit": "examples/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -436,6 +534,15 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
     if stale is not None:
         # measured on the device: updates of OTHER workers that the replica a gradient was computed on had not seen
         out["staleness_max"], out["staleness_mean"] = stale
+    if getattr(engine, "staleness_bound", None) is not None:
+        out["staleness_bound"] = engine.staleness_bound
+    if forced is not None:
+        out["forced_pulls"] = forced
+    if target is not None:
+        out["target_loss"] = target["target_loss"]
+        out["steps_to_target"] = target["steps_to_target"]
+        out["examples_to_target"] = target["examples_to_target"]
+        out["steps_to_target_detail"] = target
     return out
 
 

@@ -377,7 +377,9 @@ struct Client {
 
 }  // namespace
 
-// `bind_host`: dotted IPv4 address to listen on (the task's own entry of --ps_hosts); null or empty = every interface.
+// `bind_host`: dotted IPv4 address to listen on (the task's own entry of --ps_hosts); null or empty = the loopback
+// interface only.  The service has no authentication: it is reachable exactly where the cluster description says a ps
+// task lives ("0.0.0.0" must be asked for by name).
 DTF_RT_EXPORT void* dtf_ps_server_start_on(const char* bind_host, int port, int* actual_port) {
   std::unique_ptr<Server> s(new Server);
   s->listen_fd = ::socket(AF_INET, SOCK_STREAM, 0);
@@ -386,7 +388,7 @@ DTF_RT_EXPORT void* dtf_ps_server_start_on(const char* bind_host, int port, int*
   setsockopt(s->listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
   sockaddr_in addr{};
   addr.sin_family = AF_INET;
-  addr.sin_addr.s_addr = htonl(INADDR_ANY);
+  addr.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
   if (bind_host && *bind_host && inet_pton(AF_INET, bind_host, &addr.sin_addr) != 1) {
     ::close(s->listen_fd);
     return nullptr;

@@ -74,11 +74,19 @@ class ParameterService:
     """One ps task: owns its variables, accumulators, the token queue and global_step."""
 
     def __init__(self, port: int, num_workers: int = 0, host: str = ""):
-        """``host``: the address of this task in ``--ps_hosts``; the service listens there only (a dotted IPv4 address;
-        anything else, e.g. a host name or an empty string, listens on every interface)."""
+        """``host``: the address of this task in ``--ps_hosts``; the service listens there only.  A host name is
+        resolved to its IPv4 address; an empty string means the loopback interface; every interface has to be asked
+        for as ``0.0.0.0``."""
         self.port, self.num_workers = port, num_workers
         import re
-        self.host = host if re.fullmatch(r"\d+\.\d+\.\d+\.\d+", host or "") else ""
+        import socket
+        host = host or ""
+        if host and not re.fullmatch(r"\d+\.\d+\.\d+\.\d+", host):
+            try:
+                host = socket.gethostbyname(host)
+            except OSError as e:
+                raise OSError(f"parameter service: cannot resolve the ps host {host!r} of the cluster description") from e
+        self.host = host
         self._h = None
 
     def start(self) -> int:

@@ -85,3 +85,60 @@ def test_bench_launcher_stops_its_workers_when_it_is_told_to_stop():
     while time.time() < deadline and any(os.path.exists(f"/proc/{k}") for k in kids):
         time.sleep(0.2)
     assert not any(os.path.exists(f"/proc/{k}") for k in kids)
+
+
+def test_launcher_counts_gpus_in_sysfs_without_the_hip_runtime(tmp_path, monkeypatch):
+    """The parent's GPU count comes from the driver's topology files: nodes with SIMDs, narrowed by a visibility list."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import glob as globmod
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate([0, 256, 256, 0, 256]):                 # two CPU agents, three GPUs
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    real_glob, real_isdir = globmod.glob, os.path.isdir
+    monkeypatch.setattr(globmod, "glob", lambda pat: real_glob(str(nodes / "*" / "properties")) if "kfd" in pat else real_glob(pat))
+    monkeypatch.setattr(os.path, "isdir", lambda p: True if p == "/sys/class/kfd" else real_isdir(p))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.count_gpus_without_hip() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.count_gpus_without_hip() == 2
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "")
+    assert bench.count_gpus_without_hip() == 0
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("extra", [[], ["--config", "mlp_async"], ["--replicas_to_aggregate", "6"],
+                                   ["--replicas_to_aggregate", "12"]],
+                         ids=["sync", "async", "R6_backup_workers", "R12_two_rounds"])
+def test_bench_at_world_eight_on_cpu(extra):
+    """The world size of the target node (8 workers, /root/reference/README.md:7-15 has 4), as gloo processes: sync,
+    async, fewer replicas to aggregate than workers (two gradients dropped per update) and more (two rounds)."""
+    d = _one_json_line(_bench(["--gpus", "8", "--cpu", "--steps", "6", "--warmup", "2", "--target_loss", "0"] + extra,
+                              timeout=600))
+    assert d["n_gpus"] == 8 and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0
+    assert d["config"]["global_batch"] == 800
+    if "--replicas_to_aggregate" in extra:
+        r = int(extra[1])
+        assert f"R={r}" in d["config"]["parallelism"]
+        # examples per update = R x batch (distributed.py:92-100)
+        assert abs(d["value"] - 100 * r * 6 / (d["ms_per_step"] * 6 / 1e3)) < 1e-6 * d["value"]
+    elif extra:
+        assert d["config"]["mode"] == "async" and d["global_step"] == 1 + 8 * 8      # every worker's update counts
+    else:
+        assert d["async_global_step"] == 1 + 8 * 8
+
+
+@pytest.mark.slow
+def test_bench_reports_steps_to_target_loss():
+    """Second half of the headline metric, in the result line: steps until the printed training loss is below the
+    target.  Two sync workers average two gradients per update: never more updates than one worker needs (+ noise)."""
+    one = _one_json_line(_bench(["--gpus", "1", "--cpu", "--steps", "4", "--warmup", "1", "--target_loss", "2.2"]))
+    two = _one_json_line(_bench(["--gpus", "2", "--cpu", "--steps", "4", "--warmup", "1", "--target_loss", "2.2"]))
+    for d in (one, two):
+        assert d["target_loss"] == 2.2 and d["steps_to_target"] > 10
+        assert d["examples_to_target"] == d["steps_to_target"] * 100 * d["n_gpus"]
+    assert two["steps_to_target"] <= one["steps_to_target"] + 8
+    assert two["async_steps_to_target"] > 10 and two["async_examples_to_target"] == two["async_steps_to_target"] * 100
