@@ -52,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--no_post_update_accuracy", action="store_true")
     ap.add_argument("--graph_steps", type=int, default=0)
     ap.add_argument("--collective", default="auto",
-                    choices=["auto", "reduce_scatter", "all_reduce", "bucketed", "p2p_sharded", "p2p_replicated"])
+                    choices=["auto", "reduce_scatter", "all_reduce", "bucketed", "p2p_sharded", "p2p_replicated", "p2p_pipelined"])
     ap.add_argument("--staleness", type=int, default=None, help="async configs: pull every (staleness+1)-th step")
     ap.add_argument("--replicas_to_aggregate", type=int, default=None, help="sync configs: R (default: the number of workers)")
     ap.add_argument("--launch", default="auto", choices=["auto", "graph", "native"],

@@ -167,19 +167,12 @@ def _time_segment(engine, device, world, steps, graph_steps):
 
 
 def _select_p2p_transport(engine, prog, args, rank, world, device, graph_steps):
-    """Both peer-mapped transports move the same step over the same mapped regions; which one is faster depends on
-    the machine (link latency against link bandwidth), so it is measured here: a short timed run of each, maximum
-    over the ranks, the faster one stays.  Returns the record that goes into the result line."""
-    trial = 192
-    times = {}
-    for mode in ("replicated", "sharded"):
-        engine.set_p2p_mode(mode)
-        engine.run(trial, graph_steps)                      # captures the graphs the timed trial replays, warms the path
-        times[mode] = _time_segment(engine, device, world, trial, graph_steps)
-    best = min(times, key=times.get)                        # the same on every rank: the times are maxima over the ranks
-    engine.set_p2p_mode(best)
-    return {"steps_each": trial, "replicated_us_per_step": times["replicated"] / trial * 1e6,
-            "sharded_us_per_step": times["sharded"] / trial * 1e6, "chosen": best}
+    """The peer-mapped transports move the same update over mapped regions; which one is faster depends on the
+    machine (link latency against link bandwidth against idle CUs), so it is measured here
+    (``SyncReplicasEngine.select_transport``): a short timed run of each, maximum over the ranks, the fastest stays.
+    Parameters and counters are put back, so the warm-up and the timed run start from the initial state.  Returns the
+    record that goes into the result line."""
+    return engine.select_transport(192, graph_steps, restore=True)
 
 
 def bench_mlp_sync(args, rank, world, device, wide: bool = False):
@@ -189,7 +182,9 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     optimizer = args.optimizer or ("adam" if wide else "sgd")
     lr = 0.01 if optimizer == "sgd" else 1e-3
     train_rows = 55000 if not wide else max(8 * batch, 16384)
-    ds = mnist.synthetic_data_sets(train_size=train_rows, validation_size=100, test_size=100, seed=rank)
+    # every worker holds its own full copy of the SAME data set and draws its own batches from it (independent
+    # shuffles, no sharding by task: /root/reference/distributed.py:38, :137)
+    ds = mnist.synthetic_data_sets(train_size=train_rows, validation_size=100, test_size=100, seed=0 if not wide else rank)
     force = bool(getattr(args, "force_collectives", False)) and world == 1 and device.type == "cuda"
     if force and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -226,7 +221,6 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
             and os.environ.get("DTF_P2P_MODE") is None):
         try:
             selection = _select_p2p_transport(engine, prog, args, rank, world, device, graph_steps)
-            extra_steps = 4 * selection["steps_each"]
         except RuntimeError as e:                           # a peer wait ran into its limit: raised on every rank
             sys.stderr.write(f"[bench] rank {rank}: transport trial failed ({e})\n")
             failed, selection = 1, None
@@ -290,24 +284,19 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     target = None
     if not wide and fast and getattr(args, "target_loss", 0):
         # steps to the target loss from a fresh state (same seed), same engine settings, outside every clock
-        if engine.p2p is not None:
-            torch.cuda.synchronize()
-            engine.p2p.close()
+        engine.close_transports()
         state_t, prog_t, engine_t = build()
         if selection is not None and engine_t.p2p is not None:
             engine_t.set_p2p_mode(selection["chosen"])
         target = _steps_to_target(engine_t, prog_t, state_t, batch, R, args, rank, world, device)
-        if engine_t.p2p is not None:
-            torch.cuda.synchronize()
-            engine_t.p2p.close()
+        engine_t.close_transports()
     second = None
     if world > 1 and not wide and fast and not getattr(args, "no_second_mode", False):
         # the other update mode of the same job, timed the same way, so that one invocation yields both numbers
         transport = engine.transport
         dropped = engine.dropped
-        if engine.p2p is not None and target is None:
-            torch.cuda.synchronize()
-            engine.p2p.close()
+        if target is None:
+            engine.close_transports()
         a2 = _async_args(args)
         second = bench_mlp_async(a2, rank, world, device)
         return _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer, dtype_name, R, dt, state, prog,
@@ -333,7 +322,10 @@ def _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer
         "config": {"model": (f"wide_mlp 784-7x{hidden_units}-10" if wide else f"reference MLP 784-{hidden_units}-10"),
                    "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
                    "parallelism": (f"dp{world} sync_replicas R={R}, " +
-                                   (f"ps state sharded over {world} GPU(s) by weight-gradient tile (peer-mapped: tile -> owner, "
+                                   ("replicated SGD: every rank applies the same sums of the workers' exchanged dz1 / output-layer "
+                                    "shares (80 KB per worker and step instead of 318 KB of gradients)"
+                                    if engine.p2p_mode == "pipelined" else
+                                    f"ps state sharded over {world} GPU(s) by weight-gradient tile (peer-mapped: tile -> owner, "
                                     "updated tile -> every replica)" if engine.p2p_mode == "sharded" and engine.p2p_fused
                                     else "replicated SGD after one all-reduce (stateless optimizer, 318 KB of parameters)"
                                     if (world > 1 or force) and engine.collective == "all_reduce"
@@ -345,7 +337,9 @@ def _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer
                    "peer_mapped_allreduce": getattr(engine, "p2p", None) is not None,
                    "peer_mapped_mode": engine.p2p_mode,
                    "peer_exchange_inside_backward_launch": bool(getattr(engine, "p2p_fused", False)) and getattr(engine, "p2p", None) is not None,
-                   "step_program": ("one launch per step, pipelined (mlp_pipe.hip)" if getattr(prog, "pipe", False)
+                   "step_program": ("one launch per step, pipelined over the workers (mlp_pipe_multi.hip)"
+                                    if getattr(prog, "pipe_multi", None) is not None
+                                    else "one launch per step, pipelined (mlp_pipe.hip)" if getattr(prog, "pipe", False)
                                     else "two launches per step (mlp2_fused.hip)" if getattr(prog, "fused2", False)
                                     else "general launch sequence"),
                    "post_update_accuracy_pass": not args.no_post_update_accuracy,
@@ -453,7 +447,7 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
     shards = world if wide else 1
     # reference behaviour: every step reads the ps-resident variables (staleness 0); --staleness k pulls every (k+1)-th step
     staleness = args.staleness if getattr(args, "staleness", None) is not None else 0
-    ds = mnist.synthetic_data_sets(train_size=train_rows, validation_size=100, test_size=100, seed=rank)
+    ds = mnist.synthetic_data_sets(train_size=train_rows, validation_size=100, test_size=100, seed=0 if not wide else rank)
     force = bool(getattr(args, "force_collectives", False)) and world == 1 and device.type == "cuda" and not wide
 
     def make():

@@ -284,6 +284,29 @@ DTF_EXPORT int dtf_pipe_prime(const DtfPipeArgs* a, hipStream_t s);
 DTF_EXPORT int dtf_pipe_flush(const DtfPipeArgs* a, hipStream_t s);
 DTF_EXPORT int dtf_pipe_launch_roles(const DtfPipeArgs* a, hipStream_t s);
 
+// One-launch pipelined step for N synchronous workers of one node (mlp_pipe_multi.hip): the workers exchange dz1 of
+// their rows and their shares of the output layer's gradient through peer-mapped regions; see the file header.
+//   b.Xa   [8][world][128][ldxa]   gathered batches of EVERY worker (every rank holds the data set and every shuffle)
+//   b.ridx [8][world][ridx_len]    b.GG [2][4][world][16384]    b.D1, b.P2: unused (they live in the regions)
+//   b.lr   = learning rate / world (the mean over the workers folded in)
+// Region of a rank (uncached, IPC-exported; DTF_PIPEM_REGION_BYTES): D1 boxes [4][8][16384] floats | output-layer
+// boxes [4][8][8][2048] floats | flags [8][8] ints (step stamps).
+#define DTF_PIPEM_REGION_BYTES ((size_t)4 * 8 * 16384 * 4 + (size_t)4 * 8 * 8 * 2048 * 4 + 4096)
+struct DtfPipeMultiArgs {
+  DtfPipeArgs b;
+  char* region[8];          // exchange region of every rank as mapped into this process (own rank: the allocation)
+  const int* perm[8];       // [2][n_train] row order of every rank's shuffle (buffer = epoch & 1), on this device; null: none
+  int* err;                 // device word: set to 1 when a wait for a peer ran into its limit
+  int rank, world;
+  unsigned timeout_ticks;   // of the 100 MHz constant clock
+  int pad_;
+};
+DTF_EXPORT int dtf_pipem_step(const DtfPipeMultiArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_pipem_prime(const DtfPipeMultiArgs* a, hipStream_t s);
+DTF_EXPORT int dtf_pipem_flush(const DtfPipeMultiArgs* a, hipStream_t s);      // wait launch + flush launch
+DTF_EXPORT int dtf_pipem_launch_roles(const DtfPipeMultiArgs* a, hipStream_t s);
+DTF_EXPORT long long dtf_pipem_region_bytes(void);
+
 // C[M,N] = A[M,K] . B[N,K]^T with both operands k-contiguous (see gemm_tiled.hip).
 // dtype: 0 = fp32, 1 = bf16 (fp32 accumulate).  epilogue: 0 forward (+bias, ReLU, optional transposed copy Ct
 // and fp32 copy C32), 1 backward (mask > 0, optional Ct), 2 weight gradient (C is always fp32; bias_out = row

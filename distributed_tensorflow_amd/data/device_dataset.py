@@ -34,6 +34,32 @@ class DeviceDataset:
         self._stage_done = [None, None]       # events: the upload that last read each staging buffer has finished
         if shuffle and self.device.type == "cuda":
             self._stage = torch.zeros((2, self.n), dtype=torch.int32).pin_memory()
+        # row orders of the OTHER workers' shuffles (enable_peer_shuffles): the N-worker pipelined step gathers every
+        # worker's batches on every rank
+        self.peer_seeds = None
+        self.peer_perm = None
+        self._peer_resident = None
+        self._peer_stage = None
+        self._peer_stage_done = None
+
+    def enable_peer_shuffles(self, seeds, own: int) -> None:
+        """Keep the row order of every worker's shuffle resident (``seeds[r]`` = shuffle seed of worker r,
+        ``seeds[own]`` this worker's): every worker draws its own batches from its own full copy of the data set
+        (/root/reference/distributed.py:38, :137), and with the seeds known every rank can tell which rows they are."""
+        seeds = [int(s) for s in seeds]
+        if seeds[own] != self.seed:
+            raise ValueError("enable_peer_shuffles: seeds[own] is not this data set's shuffle seed")
+        self.peer_seeds = seeds
+        if not self.shuffle:
+            self.peer_perm = [None] * len(seeds)
+            return
+        self.peer_perm = [self.perm if r == own else torch.zeros((2, self.n), dtype=torch.int32, device=self.device)
+                          for r in range(len(seeds))]
+        self._peer_resident = [[None, None] for _ in seeds]
+        self._peer_own = own
+        if self.device.type == "cuda":
+            self._peer_stage = torch.zeros((len(seeds), 2, self.n), dtype=torch.int32).pin_memory()
+            self._peer_stage_done = [[None, None] for _ in seeds]
 
     def _upload(self, array) -> torch.Tensor:
         """Host array -> device tensor through a page-locked copy of our own, read by a KERNEL over the host link
@@ -101,3 +127,18 @@ class DeviceDataset:
                 else:
                     self.perm[e & 1].copy_(p)
                 self._resident[e & 1] = e
+            if self.peer_perm is not None:
+                for r, seed in enumerate(self.peer_seeds):
+                    if r == self._peer_own or self._peer_resident[r][e & 1] == e:
+                        continue
+                    p = torch.from_numpy(epoch_permutation(seed, e, self.n))
+                    if self._peer_stage is not None:
+                        ev = self._peer_stage_done[r][e & 1]
+                        if ev is not None:
+                            ev.synchronize()
+                        self._peer_stage[r, e & 1].copy_(p)
+                        self._peer_stage_done[r][e & 1] = self._kernel_upload(self.peer_perm[r][e & 1],
+                                                                              self._peer_stage[r, e & 1], wait=False)
+                    else:
+                        self.peer_perm[r][e & 1].copy_(p)
+                    self._peer_resident[r][e & 1] = e

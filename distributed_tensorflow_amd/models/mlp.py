@@ -148,6 +148,7 @@ class MLPProgram:
         self.async_push = None            # optional: (Mlp2Async, lr): launch 2 applies its gradients to the mapped masters
         self.shard_exchange = None        # optional: (Mlp2Shard, lr / R): launch 2 sends tiles to their owner rank, which updates
         self._eval_buf: Dict = {}
+        self.pipe_multi = None            # PipeExchange: the pipelined step of N sync workers (use_pipe_exchange)
         self._args = [self._build_args(q) for q in range(self.P)] if self.is_cuda else None
         self._started = False
         self._log_stream = None                 # stream of log reads that must not wait for later launches
@@ -176,6 +177,8 @@ class MLPProgram:
 
     def _build_args(self, q: int):
         st = self.state
+        if self.pipe_multi is not None:
+            return self._build_pipem_args(q)
         head = None if self.wide_head else ops.build_head_args(
             self.hact[-1], st.var("sm_w"), st.var("sm_b"), self.data.labels, self.R, self.B, self.loss_mode,
             rows=self.ridx[q], dz2=self.dz2, dz1=self.dz[-1], loss_part=self.loss_part, correct_part=self.correct_part,
@@ -214,6 +217,71 @@ class MLPProgram:
                 shard=self.shard_exchange[0] if self.shard_exchange is not None else None,
                 async_push=self.async_push[0] if self.async_push is not None else None)
         return out
+
+    def _build_pipem_args(self, q: int):
+        """Launch packs of the N-worker pipelined step for slot q (step, the prime launch in front of it, the flush
+        launch behind it)."""
+        st, L, x = self.state, ops._lib, self.pipe_multi
+        tail = ops.make_tail(st.state, perm=None, batch=self.B, n_train=self.data.n, gs_inc=self.gs_inc)
+
+        def pack(slot, roles, flush=False, prime=False):
+            return ops.build_pipem_args(self.data.images, self.data.labels, self.pbuf, self.ridx, st.var("hid_w"),
+                                        st.var("hid_b"), st.var("sm_w"), st.var("sm_b"), self.wlog, self.B, self.R,
+                                        self.loss_mode, slot % self.P, tail, self._pipem_lr, roles, x.regions,
+                                        self.data.peer_perm, x.err, x.rank, x.world, x.timeout_s, flush, prime)
+        return {"pipe_step": pack(q, L.PIPE_ROLE_L | L.PIPE_ROLE_Q | L.PIPE_ROLE_G | L.PIPE_ROLE_W | L.PIPE_ROLE_T),
+                "pipe_prime": pack(q - 1, L.PIPE_ROLE_Q | L.PIPE_ROLE_C, prime=True),
+                "pipe_flush": pack(q + 1, L.PIPE_ROLE_W | L.PIPE_ROLE_F, flush=True)}
+
+    def pipe_exchange_eligible(self, world: int) -> bool:
+        """Can this program run the N-worker pipelined step (``use_pipe_exchange``)?"""
+        in_dim = self.state.var(f"{self.names[0]}_w").shape[0]
+        return (self.is_cuda and type(self)._supports_mlp2 and not self.fused and self.state.optimizer == "sgd"
+                and ops.pipem_eligible(in_dim, self.hidden, self.C, self.B, world) and self.data.n >= 8 * self.B
+                and os.environ.get("DTF_PIPELINED_STEP", "1") != "0")
+
+    def use_pipe_exchange(self, exchange, lr_over_r: float) -> None:
+        """Sync mode, every update the mean of one gradient per worker: the one-launch pipelined step of N workers
+        (csrc/kernels/mlp_pipe_multi.hip).  ``exchange``: the ``PipeExchange`` with every rank's region mapped; the data
+        set must know every worker's shuffle (``DeviceDataset.enable_peer_shuffles``).  Parameters and counters carry
+        over; the next run starts with a prime launch."""
+        if not self.pipe_exchange_eligible(exchange.world):
+            raise ValueError("the N-worker pipelined step does not cover this program (shape, optimizer or world)")
+        if self.data.peer_perm is None or len(self.data.peer_perm) != exchange.world:
+            raise ValueError("the N-worker pipelined step needs every worker's shuffle (enable_peer_shuffles)")
+        in_dim = self.state.var(f"{self.names[0]}_w").shape[0]
+        dev, i32 = self.device, torch.int32
+        self.pipe, self.pipe_multi, self._pipem_lr = True, exchange, float(lr_over_r)
+        self._fused2_before_pipe = self.fused2 or getattr(self, "_fused2_before_pipe", False)
+        self.fused2 = False
+        self.peer_exchange = self.shard_exchange = self.grad_slots = self.async_push = None
+        self.schedule_tail_fn = None
+        self.P = ops._lib.PIPE_SLOTS
+        self.ridx = torch.zeros((self.P, exchange.world, max(128, (2 * self.B + 15) // 16 * 16)), dtype=i32, device=dev)
+        self.pbuf = ops.PipeMultiBuffers(in_dim, self.hidden[0], exchange.world, dev)
+        if not hasattr(self, "wlog"):
+            self.wlog = torch.zeros((self.log_cap, ops._lib.WLOG_INTS), dtype=i32, device=dev)
+        self._args = [self._build_args(q) for q in range(self.P)]
+        self._schedules.clear()
+        self._graphs.clear()
+        self._started = False
+        self._pipe_live = None
+
+    def use_two_launch(self) -> None:
+        """Back from the N-worker pipelined step to the two-launch step (the transports that exchange weight-gradient
+        tiles work on it); parameters and counters carry over."""
+        if self.pipe_multi is None:
+            return
+        dev, i32 = self.device, torch.int32
+        self.pipe, self.pipe_multi = False, None
+        self.fused2 = bool(getattr(self, "_fused2_before_pipe", False))
+        self.P = ops.MLP2_SLOTS if self.fused2 else 2
+        self.ridx = torch.zeros((self.P, max(128, (2 * self.B + 15) // 16 * 16)), dtype=i32, device=dev)
+        self._args = [self._build_args(q) for q in range(self.P)]
+        self._schedules.clear()
+        self._graphs.clear()
+        self._started = False
+        self._pipe_live = None
 
     def use_gradient_slots(self, slots) -> None:
         """Make the two-launch step write its gradients into ``slots[slot of the step]`` (flat buffers laid out
@@ -295,7 +363,7 @@ class MLPProgram:
             self._tail_cpu(q, init_only=True)
         self._started = True
 
-    def _rows_of_step(self, step: int) -> torch.Tensor:
+    def _rows_of_step(self, step: int, seed=None) -> torch.Tensor:
         """Dataset rows of the batch of 0-based local step ``step``, computed on the host (the same permutation the
         device holds) and uploaded: no device arithmetic, whose first use costs tens of milliseconds."""
         import numpy as np
@@ -308,7 +376,7 @@ class MLPProgram:
             rows = np.empty(self.B, dtype=np.int64)
             for e in np.unique(epoch):
                 m = epoch == e
-                rows[m] = epoch_permutation(self.data.seed, int(e), self.data.n)[off[m]]
+                rows[m] = epoch_permutation(self.data.seed if seed is None else seed, int(e), self.data.n)[off[m]]
         return torch.from_numpy(rows).to(self.device)
 
     def _start_pipe(self, q: int) -> None:
@@ -318,6 +386,8 @@ class MLPProgram:
         ls, B, C, b = self.steps_enqueued, self.B, self.C, self.pbuf
         in_dim = self.data.images.shape[1]
         self.data.prepare(ls, 3, B)
+        if self.pipe_multi is not None:
+            return self._start_pipe_multi(q)
         prev = None
         for j in range(4):
             slot = (q + j) % self.P
@@ -340,6 +410,39 @@ class MLPProgram:
         b.labg[before].copy_(b.labg[q])
         b.labi[before].copy_(b.labi[q])
 
+    def _start_pipe_multi(self, q: int) -> None:
+        """As ``_start_pipe``, for every worker's batches (labels: this worker's only)."""
+        ls, B, C, b, x = self.steps_enqueued, self.B, self.C, self.pbuf, self.pipe_multi
+        in_dim = self.data.images.shape[1]
+        for src in range(x.world):
+            seed = self.data.peer_seeds[src]
+            own = src == x.rank
+            prev = None
+            for j in range(4):
+                slot = (q + j) % self.P
+                rows = self._rows_of_step(ls + j, seed)
+                self.ridx[slot, src, :B] = rows.to(torch.int32)
+                self.ridx[slot, src, B:2 * B] = (rows if prev is None else prev).to(torch.int32)
+                prev = rows
+                if j == 3:
+                    break                               # the first step gathers this batch itself
+                b.xa[slot, src].zero_()
+                b.xa[slot, src, :B, :in_dim].copy_(self.data.images.index_select(0, rows))
+                b.xa[slot, src, :B, in_dim] = 1.0
+                if own:
+                    lab = self.data.labels.index_select(0, rows)
+                    b.labg[slot].zero_()
+                    b.labg[slot][:C, :B].copy_(lab.t())
+                    b.labi[slot].zero_()
+                    b.labi[slot][:B] = lab.argmax(1).to(torch.int32)
+            before = (q - 1) % self.P
+            b.xa[before, src].copy_(b.xa[q, src])
+            # (steps -2 of the first launches multiply gathered rows with zero gradients: any finite rows do)
+            b.xa[(q - 2) % self.P, src].copy_(b.xa[q, src])
+        before = (q - 1) % self.P
+        b.labg[before].copy_(b.labg[q])
+        b.labi[before].copy_(b.labi[q])
+
     def _pipe_token(self):
         """What the pipeline's working copies were built from: a change of any of these between two runs (parameters
         or counters rewritten through the state's methods or by an in-place tensor operation, steps enqueued
@@ -355,18 +458,30 @@ class MLPProgram:
         run.  Otherwise the prime launch: working copies and Q of the next step from the flat parameters."""
         if self._pipe_live == self._pipe_token():
             return
-        ops.pipe_prime(self._args[self.steps_enqueued % self.P]["pipe_prime"])
+        if self.pipe_multi is not None:
+            # every rank's boxes are zeroed by its own prime launch: nobody steps before everybody has primed (and
+            # nobody primes while a peer's steps of an earlier run could still be writing: its flush has waited for them)
+            self.pipe_multi.barrier()
+            ops.pipem_prime(self._args[self.steps_enqueued % self.P]["pipe_prime"])
+            self.pipe_multi.barrier()
+        else:
+            ops.pipe_prime(self._args[self.steps_enqueued % self.P]["pipe_prime"])
         self.pipe_primes += 1
 
     def _pipe_close(self, launched: bool = False) -> None:
         """Flush launch: the parameters after the last enqueued step into the flat buffer (``launched``: the last
         graph of the run ended with it)."""
         if not launched:
-            ops.pipe_flush(self._args[(self.steps_enqueued - 1) % self.P]["pipe_flush"])
+            self._pipe_flush_launch()
         self._pipe_live = self._pipe_token()
 
+    def _pipe_flush_launch(self) -> None:
+        args = self._args[(self.steps_enqueued - 1) % self.P]["pipe_flush"]
+        ops.pipem_flush(args) if self.pipe_multi is not None else ops.pipe_flush(args)
+
     def _pipe_step(self) -> None:
-        ops.pipe_step(self._args[self.steps_enqueued % self.P]["pipe_step"])
+        args = self._args[self.steps_enqueued % self.P]["pipe_step"]
+        ops.pipem_step(args) if self.pipe_multi is not None else ops.pipe_step(args)
         self.steps_enqueued += 1
 
     def _compute_schedule(self, q: int):
@@ -485,7 +600,7 @@ class MLPProgram:
                         # launch as well; the pipeline state carries over between graphs and between runs)
                         self._pipe_step() if self.pipe else self.enqueue_step()
                     if last and self.pipe:
-                        ops.pipe_flush(self._args[(self.steps_enqueued - 1) % self.P]["pipe_flush"])
+                        self._pipe_flush_launch()
             self.steps_enqueued = saved   # capture enqueues nothing
             self._graphs[key] = g
         return g
@@ -650,7 +765,8 @@ class MLPProgram:
     def post_correct_of_last_step(self) -> int:
         """Post-update accuracy count of the most recent step (needs one extra forward)."""
         q = self.steps_enqueued % self.P
-        rows = self.ridx[q][self.B:2 * self.B].contiguous()
+        own = self.ridx[q] if self.pipe_multi is None else self.ridx[q, self.pipe_multi.rank]
+        rows = own[self.B:2 * self.B].contiguous()
         return self._count_correct(self.data.images, self.data.labels, rows=rows, n=self.B)
 
     # ------------------------------------------------------------------ evaluation

@@ -637,6 +637,107 @@ def pipe_flush(args):
     _lib.check(_lib.kernels().dtf_pipe_flush(C.byref(args), _lib.stream_handle()), "pipe_flush")
 
 
+def pipem_eligible(in_dim, hidden, classes, batch, world) -> bool:
+    """Shapes and worlds the N-worker pipelined step of ``csrc/kernels/mlp_pipe_multi.hip`` covers: the one-worker
+    shapes, at most 8 workers, and the Gram strips of one row block of every worker within the LDS of one CU."""
+    if not (len(hidden) == 1 and hidden[0] <= 127 and classes <= 16 and batch <= 128 and in_dim % 4 == 0
+            and (in_dim + 16) // 16 <= 64 and 1 <= world <= 8):
+        return False
+    nrb = (batch + 15) // 16
+    nrb_t = 2 if nrb <= 2 else 4 if nrb <= 4 else 7 if nrb <= 7 else 8
+    return 9216 * 4 + 2 * world * nrb_t * 1024 <= 160 * 1024
+
+
+class PipeMultiBuffers:
+    """Working buffers of the N-worker pipelined step: every worker's gathered batches, the Gram matrices against
+    every worker's batches; dz1 and the output-layer shares live in the exchange regions (``DtfPipeMultiArgs``)."""
+
+    def __init__(self, in_dim, hd, world, device):
+        f32, i32 = torch.float32, torch.int32
+        self.world = world
+        self.HP = (hd + 1 + 15) // 16 * 16
+        self.KAp = (in_dim + 1 + 15) // 16 * 16
+        z = lambda *shape: torch.zeros(shape, dtype=f32, device=device)
+        self.xa = z(_lib.PIPE_SLOTS, world, 128, self.KAp)
+        self.labg = z(_lib.PIPE_SLOTS, 16, 128)
+        self.wm = z(2, self.KAp, self.HP)
+        self.w2m = z(2, self.HP, 16)
+        self.q = z(2, 16384)
+        self.z1 = z(2, 16384)
+        self.labi = torch.zeros((_lib.PIPE_SLOTS, 128), dtype=i32, device=device)
+        self.gg = z(2, 4, world, 16384)
+        self.ctr = torch.zeros((2, 2), dtype=i32, device=device)
+
+
+def build_pipem_args(x, labels, bufs, ridx, w1, b1, w2, b2, wlog, batch, rows_total, loss_mode, slot, tail, lr_over_n, roles,
+                     regions, perms, err, rank, world, timeout_s, flush=False, prime=False):
+    """Argument pack of one launch of the N-worker pipelined step.  ``regions``: device addresses of every rank's
+    exchange region as mapped here; ``perms``: one ``[2, n]`` int32 tensor per rank (the row order of its shuffle) or
+    None; ``err``: int32 device tensor whose first word the kernels set when a wait ran into ``timeout_s``;
+    ``lr_over_n``: the learning rate divided by the number of workers."""
+    in_dim, hd = w1.shape
+    c = w2.shape[1]
+    if not pipem_eligible(in_dim, [hd], c, batch, world):
+        raise ValueError("N-worker pipelined step: shape or world outside its range")
+    if rows_total not in (batch, 2 * batch):
+        raise ValueError("N-worker pipelined step: rows_total must be B or 2B")
+    if not 0 <= slot < _lib.PIPE_SLOTS or not 0 <= rank < world:
+        raise ValueError("N-worker pipelined step: slot or rank out of range")
+    if x.shape[1] != in_dim or tuple(w2.shape) != (hd, c) or b1.numel() != hd or b2.numel() != c:
+        raise ValueError("N-worker pipelined step: parameter shapes do not chain")
+    if labels.shape[1] != c or labels.shape[0] != x.shape[0]:
+        raise ValueError("N-worker pipelined step: labels do not match the dataset")
+    if bufs.world != world or bufs.HP != (hd + 1 + 15) // 16 * 16 or bufs.KAp != (in_dim + 1 + 15) // 16 * 16:
+        raise ValueError("N-worker pipelined step: working buffers were sized for another network or world")
+    if wlog.dim() != 2 or wlog.shape[1] != _lib.WLOG_INTS:
+        raise ValueError("N-worker pipelined step: wide log must be [capacity, 64]")
+    if ridx.dim() != 3 or ridx.shape[0] != _lib.PIPE_SLOTS or ridx.shape[1] != world or ridx.shape[2] < 2 * batch:
+        raise ValueError("N-worker pipelined step: row index table must be [8, world, >= 2B]")
+    if len(regions) != world or any(not r for r in regions):
+        raise ValueError("N-worker pipelined step: one mapped region per rank")
+    if len(perms) != world or any((t is None) != (perms[0] is None) for t in perms):
+        raise ValueError("N-worker pipelined step: one permutation buffer per rank, or none at all")
+    ts = (x, labels, bufs.xa, bufs.labg, bufs.wm, bufs.w2m, bufs.q, bufs.z1, bufs.gg, w1, b1, w2, b2)
+    _same_device(*ts, ridx, wlog, bufs.ctr, bufs.labi, err, *[t for t in perms if t is not None])
+    for i, t in enumerate(ts):
+        _f32c(t, f"pipe operand {i}")
+    for name, t in (("ridx", ridx), ("ctr", bufs.ctr), ("wlog", wlog), ("labi", bufs.labi), ("err", err)):
+        _i32c(t, name)
+    n_train = x.shape[0]
+    for t in perms:
+        if t is not None:
+            _i32c(t, "perm")
+            if tuple(t.shape) != (2, n_train):
+                raise ValueError("N-worker pipelined step: a permutation buffer must be [2, rows of the data set]")
+    base = _lib.PipeArgs(X=x.data_ptr(), labels=labels.data_ptr(), Xa=bufs.xa.data_ptr(), labg=bufs.labg.data_ptr(),
+                         ridx=ridx.data_ptr(), Wm=bufs.wm.data_ptr(), W2m=bufs.w2m.data_ptr(), Q=bufs.q.data_ptr(),
+                         Z1=bufs.z1.data_ptr(), labi=bufs.labi.data_ptr(), GG=bufs.gg.data_ptr(), D1=None, P2=None,
+                         ctr=bufs.ctr.data_ptr(), W1=w1.data_ptr(), b1=b1.data_ptr(), W2=w2.data_ptr(), b2=b2.data_ptr(),
+                         wlog=wlog.data_ptr(), In=in_dim, Hd=hd, C=c, B=batch, R=rows_total, HP=bufs.HP, KAp=bufs.KAp,
+                         ldxa=bufs.KAp, ldx=x.stride(0), ridx_len=ridx.shape[2], q=slot, loss_mode=loss_mode,
+                         log_cap=wlog.shape[0], roles=roles, flush=int(flush), prime=int(prime), lr=float(lr_over_n),
+                         inv_b=1.0 / batch, tail=tail)
+    out = _lib.PipeMultiArgs(b=base, err=err.data_ptr(), rank=rank, world=world,
+                             timeout_ticks=int(min(4.0e9, max(1.0, timeout_s * 1e8))), pad_=0)
+    for r in range(world):
+        out.region[r] = regions[r]
+        out.perm[r] = None if perms[r] is None else perms[r].data_ptr()
+    out._keep = (perms, err)
+    return out
+
+
+def pipem_step(args):
+    _lib.check(_lib.kernels().dtf_pipem_step(C.byref(args), _lib.stream_handle()), "pipem_step")
+
+
+def pipem_prime(args):
+    _lib.check(_lib.kernels().dtf_pipem_prime(C.byref(args), _lib.stream_handle()), "pipem_prime")
+
+
+def pipem_flush(args):
+    _lib.check(_lib.kernels().dtf_pipem_flush(C.byref(args), _lib.stream_handle()), "pipem_flush")
+
+
 def step_tail(tail, init_only=False):
     _lib.check(_lib.kernels().dtf_step_tail(C.byref(tail), int(init_only), _lib.stream_handle()), "step_tail")
 

@@ -156,6 +156,12 @@ class PipeArgs(C.Structure):
                 ("inv_b", C.c_float), ("tail", TailArgs)]
 
 
+class PipeMultiArgs(C.Structure):
+    """Mirror of ``DtfPipeMultiArgs``: the one-launch pipelined step of N synchronous workers (mlp_pipe_multi.hip)."""
+    _fields_ = [("b", PipeArgs), ("region", C.c_void_p * 8), ("perm", C.c_void_p * 8), ("err", C.c_void_p),
+                ("rank", C.c_int), ("world", C.c_int), ("timeout_ticks", C.c_uint), ("pad_", C.c_int)]
+
+
 PIPE_ROLE_L, PIPE_ROLE_Q, PIPE_ROLE_G, PIPE_ROLE_W, PIPE_ROLE_T, PIPE_ROLE_F, PIPE_ROLE_C = 1, 2, 4, 8, 16, 32, 64
 PIPE_SLOTS = 8
 
@@ -225,6 +231,11 @@ def _declare_kernels(lib):
     for name in ("dtf_pipe_step", "dtf_pipe_prime", "dtf_pipe_flush", "dtf_pipe_launch_roles"):
         getattr(lib, name).argtypes = [C.POINTER(PipeArgs), vp]
         getattr(lib, name).restype = i32
+    for name in ("dtf_pipem_step", "dtf_pipem_prime", "dtf_pipem_flush", "dtf_pipem_launch_roles"):
+        getattr(lib, name).argtypes = [C.POINTER(PipeMultiArgs), vp]
+        getattr(lib, name).restype = i32
+    lib.dtf_pipem_region_bytes.argtypes = []
+    lib.dtf_pipem_region_bytes.restype = C.c_longlong
     lib.dtf_run_schedule.argtypes = [C.POINTER(ScheduleEntry), i32, vp]
     lib.dtf_run_schedule_steps.argtypes = [C.POINTER(C.POINTER(ScheduleEntry)), C.POINTER(i32), i32, i32, i32, vp]
     lib.dtf_run_schedule_steps.restype = i32

@@ -69,10 +69,13 @@ class SyncReplicasEngine:
         # tile is summed and updated by its owner rank and stored into every replica (two hops, 2 (N-1)/N of the
         # bytes).  p2p_* name the wish; the library collective named next to it is what runs where peers cannot be mapped.
         self._want_p2p = None
+        self._p2p_pinned = collective in ("p2p_sharded", "p2p_replicated", "p2p_pipelined")
         if collective == "p2p_sharded":
             self._want_p2p, collective = "sharded", "reduce_scatter"
         elif collective == "p2p_replicated":
             self._want_p2p, collective = "replicated", "all_reduce"
+        elif collective == "p2p_pipelined":
+            self._want_p2p, collective = "pipelined", "all_reduce"
         if collective == "auto":
             small = state.nbytes() < ALLREDUCE_BELOW_BYTES and state.optimizer == "sgd"
             collective = "all_reduce" if small else "reduce_scatter"
@@ -89,10 +92,16 @@ class SyncReplicasEngine:
             raise ValueError("the replicated all-reduce path is only defined for SGD")
         self.collective = collective
         if self._want_p2p is None and collective == "all_reduce":
-            self._want_p2p = os.environ.get("DTF_P2P_MODE", "replicated")
-            if self._want_p2p not in ("replicated", "sharded"):
-                raise ValueError("DTF_P2P_MODE must be 'replicated' or 'sharded'")
+            # No measurement to go by (bench.py and the training script time the candidates on the machine and call
+            # set_p2p_mode): the one-launch pipelined step where it applies and few workers keep its Gram work small,
+            # else the sharded exchange from four workers on (two hops, 1/4 of the bytes per link), else replicated.
+            default = "pipelined" if self.world <= 4 else "sharded"
+            self._want_p2p = os.environ.get("DTF_P2P_MODE", default)
+            if self._want_p2p not in ("replicated", "sharded", "pipelined"):
+                raise ValueError("DTF_P2P_MODE must be 'replicated', 'sharded' or 'pipelined'")
         self.p2p_mode = None                    # the peer-mapped transport in use, else None
+        self.pipe_x = None                      # exchange regions of the N-worker pipelined step, once opened
+        self._pipe_refused = False
         # DTF_FORCE_GENERAL_SYNC=1: R == workers through the general (stamped, chief-selected) path as well
         self.fast = self.R == self.world and os.environ.get("DTF_FORCE_GENERAL_SYNC", "0") != "1"
         self.arrival_delay = arrival_delay      # test hook: artificial per-step compute delay of this rank (host path)
@@ -200,7 +209,8 @@ class SyncReplicasEngine:
         import socket
         st, prog = self.state, self.program
         # "auto": real multi-rank RCCL groups only; "1": also one-rank groups and gloo rehearsals
-        wanted = p2p.requested("") or (p2p.requested(self.coll.backend) and self.world > 1)
+        wanted = (p2p.requested("") or (p2p.requested(self.coll.backend) and self.world > 1)
+                  or (self._p2p_pinned and os.environ.get("DTF_P2P_ALLREDUCE", "auto") != "0"))
         eligible = (self._want_p2p is not None and st.optimizer in ("sgd", "adam") and self.world <= 8
                     and getattr(prog, "fused2", False) and not prog.fused and prog.P == p2p.SLOTS)
         fused = os.environ.get("DTF_P2P_FUSED", "1") != "0" and not (os.environ.get("DTF_SHARE_GPU") == "1" and self.world > 3)
@@ -211,6 +221,9 @@ class SyncReplicasEngine:
             return False
         self.p2p_fused = os.environ.get("DTF_P2P_FUSED", "1") != "0"
         self.p2p_mode = "sharded" if st.optimizer == "adam" else self._want_p2p
+        if self.p2p_mode == "pipelined" and not self._open_pipe(group):
+            # (the same answer on every rank) shape, optimizer, data set or mapping rule the pipelined step out
+            self.p2p_mode = "sharded" if self.world >= 4 else "replicated"
         self._adam = None
         if st.optimizer == "adam":
             # ps-resident slot variables: flat moment buffers on every rank, of which a rank only ever touches the
@@ -288,9 +301,54 @@ class SyncReplicasEngine:
         self.p2p_mode = "general"
         return True
 
+    def _open_pipe(self, group) -> bool:
+        """Exchange regions and data-set knowledge of the N-worker pipelined step (collective; every rank gets the same
+        answer): the update must be the mean of one gradient per worker with SGD, the program's shape in range, every
+        rank on one node with the SAME data set (every worker holds its own full copy, /root/reference/distributed.py:38)
+        - a rank gathers its peers' batches itself, from their shuffle seeds."""
+        from .pipe_exchange import PipeExchange, PipeExchangeUnavailable
+        import warnings
+        if self.pipe_x is not None:
+            return True
+        if self._pipe_refused:
+            return False
+        st, prog = self.state, self.program
+        ok = (self.fast and st.optimizer == "sgd" and hasattr(prog, "pipe_exchange_eligible")
+              and prog.pipe_exchange_eligible(self.world))
+        seeds = [prog.data.seed]
+        if self.world > 1:
+            digest = None
+            if ok:
+                d = prog.data
+                digest = (int(d.n), float(d.images[:: max(1, d.n // 64)].double().sum().item()),
+                          float(d.labels[:: max(1, d.n // 64)].double().sum().item()), bool(d.shuffle))
+            seen = [None] * self.world
+            dist.all_gather_object(seen, (ok, digest, int(prog.data.seed)), group=group)
+            ok = all(x[0] for x in seen) and all(x[1] == seen[0][1] for x in seen)
+            seeds = [x[2] for x in seen]
+        if ok:
+            try:
+                self.pipe_x = PipeExchange(st.device, self.coll.rank if self.coll is not None else 0, self.world, group)
+            except PipeExchangeUnavailable as e:            # raised on every rank together
+                warnings.warn(f"pipelined exchange unavailable ({e})")
+                ok = False
+        if ok:
+            prog.data.enable_peer_shuffles(seeds, self.pipe_x.rank)
+        self._pipe_refused = not ok
+        return ok
+
     def _wire_p2p(self) -> None:
         from . import p2p_allreduce as p2p
         st, prog = self.state, self.program
+        if self.p2p_mode == "pipelined":
+            # one launch per step: the row workgroups exchange dz1 and the output layer's shares with every rank and
+            # every rank applies the same sums to its own replica (mlp_pipe_multi.hip)
+            prog.schedule_tail_fn = None
+            prog.use_pipe_exchange(self.pipe_x, st.lr / self.R)
+            prog.after_compute = None
+            return
+        if getattr(prog, "pipe_multi", None) is not None:
+            prog.use_two_launch()
         if self.p2p_fused and self.p2p_mode == "sharded":
             # the backward launch sends every tile to its owner rank, which updates it and stores it into every replica
             prog.schedule_tail_fn = None
@@ -318,12 +376,110 @@ class SyncReplicasEngine:
         with the device idle).  Both work on the same mapped regions; parameters and counters carry over."""
         if self.p2p is None:
             raise RuntimeError("no peer-mapped transport is installed")
-        if mode not in ("replicated", "sharded"):
-            raise ValueError("mode must be 'replicated' or 'sharded'")
+        if mode not in ("replicated", "sharded", "pipelined"):
+            raise ValueError("mode must be 'replicated', 'sharded' or 'pipelined'")
         if mode != "sharded" and getattr(self, "_adam", None) is not None:
             raise ValueError("Adam runs on the sharded exchange only (the owner of a tile keeps its moments)")
+        if mode == "pipelined" and not self._open_pipe(self.coll.group if self.coll is not None else None):
+            raise ValueError("the N-worker pipelined step does not apply to this job (shape, optimizer, R != workers, "
+                             "different data sets on the ranks, or regions that cannot be mapped)")
         self.p2p_mode = mode
         self._wire_p2p()
+
+    def close_transports(self) -> None:
+        """Unmap and release the peer-mapped regions (collective when there are peers: nobody may still be writing)."""
+        if self.p2p is None and self.pipe_x is None:
+            return
+        torch.cuda.synchronize(self.state.device)
+        if self.world > 1:
+            if self.coll.backend == "nccl":
+                dist.barrier(group=self.coll.group, device_ids=[self.state.device.index])
+            else:
+                dist.barrier(group=self.coll.group)
+        if self.pipe_x is not None:
+            self.pipe_x.close()
+            self.pipe_x = None
+        if self.p2p is not None:
+            self.p2p.close()
+
+    def p2p_candidates(self):
+        """Peer-mapped transports this job could run (collective: may open the pipelined exchange)."""
+        if self.p2p is None:
+            return []
+        if getattr(self, "_adam", None) is not None:
+            return ["sharded"]
+        out = ["replicated", "sharded"]
+        if self._open_pipe(self.coll.group if self.coll is not None else None):
+            out.append("pipelined")
+        return out
+
+    def _transport_late(self) -> bool:
+        """Did a wait for a peer run into its limit (either family of regions)?  Synchronises with the device."""
+        late = self.p2p.timed_out() if self.p2p is not None else False
+        if self.pipe_x is not None and self.pipe_x.timed_out():
+            late = True
+        return late
+
+    def select_transport(self, trial_steps: int = 192, graph_steps: int = 64, restore: bool = True):
+        """Time every candidate transport on the machine the job runs on (collective) and keep the fastest: which of
+        one hop with all the bytes, two hops with a fraction of them, or the one-launch step with its Gram work wins
+        depends on link latency against link bandwidth against idle CUs, i.e. on the node.  Each candidate runs
+        ``trial_steps`` steps to capture its graphs and ``trial_steps`` timed ones (maximum over the ranks).  With
+        ``restore`` parameters and counters are put back afterwards, so a training run starts where it would have.
+        A pipelined trial whose wait for a peer runs into its limit is recorded as failed and skipped; the tile
+        transports keep their behaviour (the error is raised on every rank).  Returns the record for logs."""
+        import time as _time
+        st, prog = self.state, self.program
+        cands = self.p2p_candidates()
+        if len(cands) < 2:
+            return None
+        keep_p, keep_s = st.params.clone(), st.state.clone()
+        keep_applied = self.updates_applied
+        nccl = self.world > 1 and self.coll.backend == "nccl"
+
+        def sync_all():
+            torch.cuda.synchronize(st.device)
+            if self.world > 1:
+                dist.barrier(group=self.coll.group, device_ids=[st.device.index]) if nccl else dist.barrier(group=self.coll.group)
+            torch.cuda.synchronize(st.device)
+
+        times = {}
+        for mode in cands:
+            try:
+                self.set_p2p_mode(mode)
+                self.run(trial_steps, graph_steps)              # captures the graphs the timed trial replays
+                sync_all()
+                t0 = _time.perf_counter()
+                self.run(trial_steps, graph_steps, defer_checks=True)
+                torch.cuda.synchronize(st.device)
+                dt = _time.perf_counter() - t0
+                sync_all()
+                self.run_checks()
+                if self.world > 1:
+                    t = torch.tensor([dt], dtype=torch.float64, device=st.device if nccl else "cpu")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.coll.group)
+                    dt = float(t.item())
+                times[mode] = dt
+            except RuntimeError:
+                if mode != "pipelined":
+                    raise
+                # raised on every rank together (the ranks agree on time-outs): forget the pipelined step for this job
+                torch.cuda.synchronize(st.device)
+                self.pipe_x.err.zero_()
+                times[mode] = float("inf")
+        best = min(times, key=times.get)                        # the same on every rank: maxima over the ranks
+        self.set_p2p_mode(best)
+        if restore:
+            torch.cuda.synchronize(st.device)
+            st.params.copy_(keep_p)
+            st.state.copy_(keep_s)
+            st.values_version += 1
+            self.updates_applied = keep_applied
+            prog._started = False
+        rec = {"steps_each": trial_steps, "chosen": best}
+        for mode, dt in times.items():
+            rec[f"{mode}_us_per_step"] = (dt / trial_steps * 1e6) if dt != float("inf") else None
+        return rec
 
     # ---- Adam on the sharded exchange: moments between the owners' buffers and the checkpointable slices
     def publish_state(self) -> None:
@@ -362,6 +518,9 @@ class SyncReplicasEngine:
                     "accepted-rank mask summed in rank order)")
         if not self.use_coll:
             return "none (one worker)"
+        if self.p2p is not None and self.p2p_mode == "pipelined":
+            return ("peer-mapped pipelined exchange over xGMI (one launch per step: dz1 and the output layer's shares "
+                    "-> every rank's boxes, every rank applies the same sums to its replica)")
         if self.p2p is not None:
             where = "inside the backward launch" if self.p2p_fused else "separate update launch"
             if self.p2p_fused and self.p2p_mode == "sharded":
@@ -391,6 +550,15 @@ class SyncReplicasEngine:
         if all(d == seen[0] for d in seen):
             return
         import warnings
+        if self.p2p_mode == "pipelined":
+            warnings.warn("the pipelined exchange left the replicas different on this machine; continuing from rank 0's "
+                          "parameters with the separate update launch")
+            self.p2p_mode, self.p2p_fused, self._pipe_refused = "replicated", False, True
+            self.coll.broadcast(p, src=0)
+            self.state.values_version += 1
+            self._wire_p2p()
+            self._replica_checks_left = 1
+            return
         if not self.p2p_fused:
             raise RuntimeError(f"peer-mapped all-reduce: replicas differ after the update ({seen})")
         warnings.warn("peer exchange inside the backward launch left the replicas different on this machine; "
@@ -458,7 +626,7 @@ class SyncReplicasEngine:
                 self.program.run(n_steps, graph_steps)
             self.updates_applied += n_steps
             if self.p2p is not None:
-                late = self.p2p.timed_out()
+                late = self._transport_late()
                 self._runs_since_check += 1
                 if self.world > 1 and self._runs_since_check >= self._replica_check_every:
                     self._replica_checks_left = max(self._replica_checks_left, 1)      # periodic: same call count everywhere
@@ -495,7 +663,7 @@ class SyncReplicasEngine:
         if not getattr(self, "_checks_owed", False):
             return
         self._checks_owed = False
-        late = self.p2p.timed_out()
+        late = self._transport_late()
         if self.fast:
             self._runs_since_check += 1
             if self.world > 1 and self._runs_since_check >= self._replica_check_every:
