@@ -42,6 +42,20 @@
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 
+// Diagnostic build only (-DDTF_STAMPS): per-workgroup timestamps of the 100 MHz constant clock.
+#ifdef DTF_STAMPS
+__device__ unsigned long long* pipem_stamp_buf = nullptr;
+#define PM_STAMP(slot)                                                                                                           \
+  do {                                                                                                                           \
+    if (threadIdx.x == 0 && pipem_stamp_buf) pipem_stamp_buf[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+extern "C" __attribute__((visibility("default"))) int dtf_set_stamp_buffer_pipem(unsigned long long* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(pipem_stamp_buf), &p, sizeof(p));
+}
+#else
+#define PM_STAMP(slot) do { } while (0)
+#endif
+
 #define PM_GENS 4
 #define PM_MAXR 8
 #define PM_P2_BLK 2048                                   // floats per (generation, source, row block) of the output-layer boxes
@@ -65,6 +79,14 @@ __device__ __forceinline__ float* pm_gg(const DtfPipeMultiArgs& m, int gen, int 
 }
 __device__ __forceinline__ int* pm_ridx(const DtfPipeMultiArgs& m, int slot, int src) {
   return m.b.ridx + ((size_t)(slot & (PIPE_SLOTS - 1)) * m.world + src) * m.b.ridx_len;
+}
+
+// 16-byte load of box contents: system scope (sc0 sc1), served by memory whatever a cache may still hold of the same
+// address from four steps ago.  The boxes live in uncached memory; with every read of them marked like this no cache
+// invalidation (an acquire fence costs one per waiting wave) is needed between seeing a flag and reading the boxes.
+__device__ __forceinline__ void pm_bld4_sys(rsrc_t r, unsigned voff, unsigned soff, float (&v)[4]) {
+  auto t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 17);
+  v[0] = __uint_as_float(t[0]); v[1] = __uint_as_float(t[1]); v[2] = __uint_as_float(t[2]); v[3] = __uint_as_float(t[3]);
 }
 
 // 16-byte store that goes straight to memory, wherever it lives (own region or a peer's over xGMI)
@@ -92,7 +114,7 @@ __host__ __device__ __forceinline__ PmDims pm_dims(const DtfPipeMultiArgs& m, in
   d.tpw = 16 / d.ks;
   d.nL = (p.roles & PIPE_ROLE_L) ? nrb * (1 + post) : 0;
   d.nQ = (p.roles & PIPE_ROLE_Q) ? nrb * (1 + (p.prime ? post : 0)) * d.NT : 0;
-  d.nG = (p.roles & PIPE_ROLE_G) ? 4 * m.world * nrb * nrb : 0;
+  d.nG = (p.roles & PIPE_ROLE_G) ? 4 * m.world * nrb * ((nrb + 1) / 2) : 0;
   d.nW = (p.roles & PIPE_ROLE_W) ? (d.KT * d.NT + d.tpw - 1) / d.tpw : 0;
   d.nT = (p.roles & PIPE_ROLE_T) ? m.world * ((p.B + 7) >> 3) : 0;
   d.nF = (p.roles & PIPE_ROLE_F) ? 1 : 0;
@@ -124,7 +146,10 @@ __device__ __forceinline__ void pm_flag_wait(const DtfPipeMultiArgs& m, int nrb,
       __builtin_amdgcn_s_sleep(1);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");        // the boxes are read after the flags
+  // The boxes are read after the flags: the flag values have returned (they were just compared), the box loads are
+  // issued behind this line and go to memory (pm_bld4_sys); nothing for the compiler to move across it.
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -140,7 +165,7 @@ __device__ __forceinline__ void pm_load_d(const DtfPipeMultiArgs& m, int gen, in
     const bool on = active && src < m.world;
     const rsrc_t rd = make_rsrc(pm_d1(m.region[m.rank], gen, on ? src : 0), PIPE_MAT * 4u);
 #pragma unroll
-    for (int jb = 0; jb < NRB; ++jb) bld4(rd, on ? pipe_frag(tile, jb, lane) * 4u : kOOB, db[u][jb]);
+    for (int jb = 0; jb < NRB; ++jb) pm_bld4_sys(rd, on ? pipe_frag(tile, jb, lane) * 4u : kOOB, 0, db[u][jb]);
   }
 }
 // acc += strip(kind slot kk, source) . D tiles, A operands from the LDS strips
@@ -171,6 +196,7 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
   float (*dzs)[17] = reinterpret_cast<float (*)[17]>(smem + 2176 + 2176 + 2048);      // [16][17]     dz2 of the 16 rows
   float* row_loss = smem + 2176 + 2176 + 2048 + 272;                                  // [16]
   int* row_hit = reinterpret_cast<int*>(row_loss + 16);                               // [16]
+  float (*acca)[4][64] = reinterpret_cast<float (*)[4][64]>(smem + 6704);             // [8][4][64]  D(s-2) term of each tile
   float* strips = smem + PM_SMEM_BASE;                                                // [kinds][world][NRB][256]
 
   const int tid = threadIdx.x;
@@ -190,6 +216,7 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
   const int tile = t_wave ? wave : (o_wave ? wave - 8 : 0);
   const int n0 = tile * 16;
   const int col = n0 + fr;
+  PM_STAMP(0);
 
   // ---- stage 0: the Gram strips of this row block into LDS, all 16 waves (training rows: against D(s-2) then against
   //      D(s-1); accuracy-only rows: G(s-1,s-1) against D(s-1)) ----
@@ -204,42 +231,52 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
     lds_byte_t* dst = (lds_byte_t*)(strips) + (size_t)t * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rgs, dst, 16, (int)(pipe_frag(rb, jb, lane) * 4u), 0, 0, 0);
   }
-  // ---- every load that does not depend on the flags ----
+  // ---- the step counter and a first look at the flags (the stamps of step s-1 are the step counter of this step),
+  //      then every load that does not depend on the flags ----
+  const rsrc_t rctr = make_rsrc(p.ctr, 16u);
+  const int ls = bldi(rctr, (unsigned)(2 * a + 1) * 4u);
+  const bool waits = t_wave || o_wave;
+  int seen = 0;
+  if (waits) seen = pm_flag_peek(m, NRB, ls, lane);
   const rsrc_t rq = make_rsrc(post ? p.Z1 + (size_t)pg * PIPE_MAT : p.Q + (size_t)a * PIPE_MAT, PIPE_MAT * 4u);
   float qv[4], db[2][NRB][4];
   bld4(rq, t_wave ? pipe_frag(rb, tile, lane) * 4u : kOOB, qv);
-  pm_load_d<NRB>(m, g2, 0, tile, t_wave && !post, lane, db);
+  pm_load_d<NRB>(m, g2, 0, tile, o_wave && !post, lane, db);       // (the output-layer wave of the tile runs the D(s-2) term)
   const int srow = tid >> 4;                          // threads [0,256): row srow, class fr
   const int lslot = post ? ((p.q + PIPE_SLOTS - 1) & (PIPE_SLOTS - 1)) : p.q;
   const rsrc_t rlab = make_rsrc(p.labg + lslot * PIPE_LABG_SLOT, PIPE_LABG_SLOT * 4u);
   const rsrc_t rli = make_rsrc(p.labi + lslot * PIPE_ROWS, PIPE_ROWS * 4u);
-  const rsrc_t rctr = make_rsrc(p.ctr, 16u);
   const float lab = bld(rlab, tid < 256 ? (unsigned)(fr * PIPE_ROWS + m0 + srow) * 4u : kOOB);
   const int lab_class = bldi(rli, tid < 256 ? (unsigned)(m0 + srow) * 4u : kOOB);
-  const int ls = bldi(rctr, (unsigned)(2 * a + 1) * 4u);
   const unsigned blk4 = (unsigned)p.HP * 64u;
   const rsrc_t rw2 = make_rsrc(p.W2m + (size_t)pg * p.HP * 16, blk4);
   float w2o[4];
   bld4(rw2, o_wave ? (unsigned)(tile * 64 + lane) * 16u : kOOB, w2o);
-  // first look at the flags (the stamps of step s-1 are the step counter of this step)
-  const bool waits = t_wave || o_wave;
-  int seen = 0;
-  if (waits) seen = pm_flag_peek(m, NRB, ls, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  // (Asking for the boxes of step s-1 right here when the first look finds every flag set was tried: the barrier
+  // below then waits for that second round trip to uncached memory too, the D(s-2) term starts later and the row
+  // workgroup ends 0.8 us later, not earlier.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                     // the strips are in LDS
+  PM_STAMP(1);
   if (!(wave < (NT > 4 ? NT : 4) || o_wave)) return;   // (waves 0..3 also carry the softmax rows)
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  // ---- correction for D(s-2): nothing of this launch is needed ----
-  if (t_wave && !post) {
+  // ---- correction for D(s-2): nothing of this launch is needed; it runs on the tile's output-layer wave while the
+  //      tile wave is already after the boxes of step s-1, and travels to the tile wave through LDS ----
+  if (o_wave && !post) {
     pm_correct<NRB>(m, strips, 0, 0, lane, db, acc0, acc1);
     for (int s0 = 2; s0 < world; s0 += 2) {
       pm_load_d<NRB>(m, g2, s0, tile, true, lane, db);
       pm_correct<NRB>(m, strips, 0, s0, lane, db, acc0, acc1);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acca[tile][r][lane] = acc0[r] + acc1[r];
   }
+  PM_STAMP(2);
   // ---- the boxes of step s-1 ----
   if (waits) pm_flag_wait(m, NRB, ls, lane, seen);
+  PM_STAMP(3);
   if (t_wave) {
     // correction for D(s-1) (accuracy-only rows: the only one)
     const int kk = post ? 0 : 1;
@@ -257,7 +294,7 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
       const rsrc_t rp2 = make_rsrc(pm_p2(mine, g1, src, 0), 8u * PM_P2_BLK * 4u);
       float part[NRB][4];
 #pragma unroll
-      for (int k = 0; k < NRB; ++k) pipe_bld4_s(rp2, (unsigned)(tile * 64 + lane) * 16u, (unsigned)k * PM_P2_BLK * 4u, part[k]);
+      for (int k = 0; k < NRB; ++k) pm_bld4_sys(rp2, (unsigned)(tile * 64 + lane) * 16u, (unsigned)k * PM_P2_BLK * 4u, part[k]);
 #pragma unroll
       for (int k = 0; k < NRB; ++k)
 #pragma unroll
@@ -274,10 +311,12 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
       *reinterpret_cast<f32x4*>(p.W2m + (size_t)a * p.HP * 16 + (size_t)(tile * 64 + lane) * 4) = w4;
     }
   }
+  PM_STAMP(4);
+  __syncthreads();                                     // U(s) rows and the D(s-2) terms of every tile are in LDS
   if (t_wave) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      zv[r] = qv[r] - p.lr * (acc0[r] + acc1[r]);
+      zv[r] = qv[r] - p.lr * ((post ? 0.f : acca[tile][r][lane]) + (acc0[r] + acc1[r]));
       // column Hd of h' is the constant 1 that carries b2; columns beyond it do not exist
       hreg[r] = col < p.Hd ? fmaxf(zv[r], 0.f) : (col == p.Hd ? 1.f : 0.f);
       hs[tile][4 * g + r][fr] = hreg[r];
@@ -287,9 +326,10 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
       *reinterpret_cast<f32x4*>(p.Z1 + (size_t)a * PIPE_MAT + pipe_frag(rb, tile, lane)) = z4;
     }
   }
-  __syncthreads();                                     // U(s) rows of every tile are in LDS
-  // ---- stage 2: partial logits of the tile's 16 hidden columns ----
+  // ---- stage 2: partial logits of the tile's 16 hidden columns (the wave reads back only its own h tile: LDS
+  //      operations of one wave execute in order, no workgroup barrier needed) ----
   float w2b[4] = {0.f, 0.f, 0.f, 0.f}, ha[4] = {0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_wave_barrier();
   if (t_wave) {
     f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
     // (MFMA step j takes hidden column n0 + 4g + j)
@@ -308,6 +348,7 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
     }
   }
   __syncthreads();
+  PM_STAMP(5);
   // ---- stage 3: loss, accuracy, dz2 of the 16 rows (16 lanes per row) ----
   if (tid < 256) {
     float zt[8];
@@ -328,6 +369,7 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
     }
   }
   __syncthreads();
+  PM_STAMP(6);
   if (wave == 8) {
     // the row block's log entries, added up in row order by a wave that has nothing else left to do
     if (lane == 0) {
@@ -382,6 +424,7 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
   __syncthreads();                                     // (the waves that are left: the tile waves)
   if (wave == 0 && lane < world)
     __hip_atomic_store(pm_flags(m.region[lane]) + m.rank * 8 + rb, ls + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  PM_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -439,7 +482,7 @@ __device__ __forceinline__ void pm_role_q(const DtfPipeMultiArgs& m, int idx, fl
         const rsrc_t rg = make_rsrc(pm_gg(m, pg, 3, src), PIPE_MAT * 4u);
         const rsrc_t rd = make_rsrc(pm_d1(m.region[m.rank], g2, src), PIPE_MAT * 4u);
         bld4(rg, pipe_frag(rb, jb, lane) * 4u, av[i]);
-        bld4(rd, pipe_frag(nt, jb, lane) * 4u, bv[i]);
+        pm_bld4_sys(rd, pipe_frag(nt, jb, lane) * 4u, 0, bv[i]);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) av[i][j] = bv[i][j] = 0.f;
@@ -466,21 +509,24 @@ __device__ __forceinline__ void pm_role_q(const DtfPipeMultiArgs& m, int idx, fl
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// role G: one 16x16 tile of a Gram matrix (rows: this rank's batch, columns: a source rank's batch)
+// role G: two adjacent 16x16 tiles of a Gram matrix (rows: this rank's batch, columns: a source rank's batch) per
+// 16-wave workgroup, split-K over the waves; the A operand (this rank's rows) is loaded once for both tiles
 // ---------------------------------------------------------------------------------------------------------
 template <int NRB>
 __device__ __forceinline__ void pm_role_g(const DtfPipeMultiArgs& m, int idx, float* smem) {
   const DtfPipeArgs& p = m.b;
-  float (*red)[4][64] = reinterpret_cast<float (*)[4][64]>(smem);
+  float (*red)[16][4][64] = reinterpret_cast<float (*)[16][4][64]>(smem);      // [2 tiles][16 waves][4][64]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, g = lane >> 4;
-  const int per = NRB * NRB;
+  constexpr int NP = (NRB + 1) / 2;                    // column pairs per row of tiles
+  const int per = NRB * NP;
   const int ks = idx / per;                            // kind * world + source
   const int kind = ks / m.world, src = ks - kind * m.world;
   const int rem = idx - ks * per;
-  const int rbi = rem / NRB, cbj = rem - rbi * NRB;
-  const int m0 = rbi * 16, n0 = cbj * 16;
+  const int rbi = rem / NP, cb0 = 2 * (rem - rbi * NP);
+  const bool two = cb0 + 1 < NRB;                      // (odd NRB: the last pair is a single tile)
+  const int m0 = rbi * 16, n0 = cb0 * 16;
   const int a = p.q & 1;
   // kinds: G(s,s), G(s+1,s), G(s+1,s-1), G(s+2,s-1)
   const int slot_a = p.q + (kind == 0 ? 0 : kind == 3 ? 2 : 1);
@@ -489,31 +535,37 @@ __device__ __forceinline__ void pm_role_g(const DtfPipeMultiArgs& m, int idx, fl
   const rsrc_t ra = make_rsrc(pm_xa(m, slot_a, m.rank), slot_bytes);
   const rsrc_t rb = make_rsrc(pm_xa(m, slot_b, src), slot_bytes);
   const int nX = p.KAp >> 4;
-  float av[4][4], bv[4][4];
+  float av[4][4], bv[2][4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = wave + 16 * i;
     const unsigned k4 = (unsigned)(16 * c + 4 * g) * 4u;
     bld4(ra, c < nX ? (unsigned)(m0 + fr) * (unsigned)p.ldxa * 4u + k4 : kOOB, av[i]);
-    bld4(rb, c < nX ? (unsigned)(n0 + fr) * (unsigned)p.ldxa * 4u + k4 : kOOB, bv[i]);
-  }
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    acc0 = MFMA16(av[i][0], bv[i][0], acc0);
-    acc1 = MFMA16(av[i][1], bv[i][1], acc1);
-    acc0 = MFMA16(av[i][2], bv[i][2], acc0);
-    acc1 = MFMA16(av[i][3], bv[i][3], acc1);
+    bld4(rb, c < nX ? (unsigned)(n0 + fr) * (unsigned)p.ldxa * 4u + k4 : kOOB, bv[0][i]);
+    bld4(rb, (c < nX && two) ? (unsigned)(n0 + 16 + fr) * (unsigned)p.ldxa * 4u + k4 : kOOB, bv[1][i]);
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc0[r] + acc1[r];
+  for (int t = 0; t < 2; ++t) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc0 = MFMA16(av[i][0], bv[t][i][0], acc0);
+      acc1 = MFMA16(av[i][1], bv[t][i][1], acc1);
+      acc0 = MFMA16(av[i][2], bv[t][i][2], acc0);
+      acc1 = MFMA16(av[i][3], bv[t][i][3], acc1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[t][wave][r][lane] = acc0[r] + acc1[r];
+  }
   __syncthreads();
-  if (threadIdx.x < 256) {
+  if (threadIdx.x < 512) {
+    const int t = threadIdx.x >> 8;
+    if (t == 1 && !two) return;
     const int e_r = (threadIdx.x >> 6) & 3, e_ln = threadIdx.x & 63;
     const int e_rl = 4 * (e_ln >> 4) + e_r, e_cl = e_ln & 15;
-    const float s = pipe_reduce16(red, e_r, e_ln);
+    const float s = pipe_reduce16(red[t], e_r, e_ln);
     float* out = pm_gg(m, a, kind, src);
-    out[pipe_frag(rbi, cbj, (e_cl >> 2) * 16 + e_rl) + (e_cl & 3)] = s;       // A-operand layout
+    out[pipe_frag(rbi, cb0 + t, (e_cl >> 2) * 16 + e_rl) + (e_cl & 3)] = s;   // A-operand layout
   }
 }
 
@@ -553,7 +605,7 @@ __device__ __forceinline__ void pm_role_w(const DtfPipeMultiArgs& m, int idx, fl
       float av[NRB][4], bv[NRB][4];
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) {
-        bld4(rd, valid ? pipe_frag(nt, rb, lane) * 4u : kOOB, bv[rb]);
+        pm_bld4_sys(rd, valid ? pipe_frag(nt, rb, lane) * 4u : kOOB, 0, bv[rb]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) av[rb][j] = pipe_bld_s(rx, valid ? a_base : kOOB, (unsigned)(16 * rb + j) * ldx4);
       }
@@ -676,7 +728,7 @@ __device__ __forceinline__ void pm_role_f(const DtfPipeMultiArgs& m) {
     for (int src = 0; src < m.world; ++src) {
       const float* box = pm_p2(m.region[m.rank], g1, src, 0);
 #pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) s += box[(size_t)rb * PM_P2_BLK + e];
+      for (int rb = 0; rb < NRB; ++rb) s += __hip_atomic_load(box + (size_t)rb * PM_P2_BLK + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const float w = p.W2m[(size_t)pg * p.HP * 16 + e] - p.lr * s;
     const int ln = (e >> 2) & 63;

@@ -89,7 +89,7 @@ class PipeExchange:
     def barrier(self) -> None:
         """Device idle here, then every rank: what the prime launch wrote is in place everywhere before a step runs."""
         torch.cuda.synchronize(self.device)
-        if self.world > 1:
+        if self.world > 1 and dist.is_initialized():
             if dist.get_backend(self.group) == "nccl":
                 dist.barrier(group=self.group, device_ids=[self.device.index])
             else:
