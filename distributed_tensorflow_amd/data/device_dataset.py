@@ -122,7 +122,9 @@ class DeviceDataset:
                     ev = self._stage_done[e & 1]
                     if ev is not None:
                         ev.synchronize()
-                    self._stage[e & 1].copy_(p)
+                    # (a plain memory copy through NumPy: a tensor copy wakes the CPU thread pool, which takes tens of
+                    # milliseconds when several workers share the host's cores)
+                    self._stage[e & 1].numpy()[:] = p.numpy()
                     self._stage_done[e & 1] = self._kernel_upload(self.perm[e & 1], self._stage[e & 1], wait=False)
                 else:
                     self.perm[e & 1].copy_(p)
@@ -136,7 +138,7 @@ class DeviceDataset:
                         ev = self._peer_stage_done[r][e & 1]
                         if ev is not None:
                             ev.synchronize()
-                        self._peer_stage[r, e & 1].copy_(p)
+                        self._peer_stage[r, e & 1].numpy()[:] = p.numpy()
                         self._peer_stage_done[r][e & 1] = self._kernel_upload(self.peer_perm[r][e & 1],
                                                                               self._peer_stage[r, e & 1], wait=False)
                     else:

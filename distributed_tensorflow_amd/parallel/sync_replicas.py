@@ -448,17 +448,21 @@ class SyncReplicasEngine:
             try:
                 self.set_p2p_mode(mode)
                 self.run(trial_steps, graph_steps)              # captures the graphs the timed trial replays
-                sync_all()
-                t0 = _time.perf_counter()
-                self.run(trial_steps, graph_steps, defer_checks=True)
-                torch.cuda.synchronize(st.device)
-                dt = _time.perf_counter() - t0
-                sync_all()
-                self.run_checks()
-                if self.world > 1:
-                    t = torch.tensor([dt], dtype=torch.float64, device=st.device if nccl else "cpu")
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.coll.group)
-                    dt = float(t.item())
+                best_dt = None
+                for _ in range(2):                              # the better of two: a host hiccup does not decide
+                    sync_all()
+                    t0 = _time.perf_counter()
+                    self.run(trial_steps, graph_steps, defer_checks=True)
+                    torch.cuda.synchronize(st.device)
+                    dt = _time.perf_counter() - t0
+                    sync_all()
+                    self.run_checks()
+                    if self.world > 1:
+                        t = torch.tensor([dt], dtype=torch.float64, device=st.device if nccl else "cpu")
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.coll.group)
+                        dt = float(t.item())
+                    best_dt = dt if best_dt is None else min(best_dt, dt)
+                dt = best_dt
                 times[mode] = dt
             except RuntimeError:
                 if mode != "pipelined":
