@@ -447,6 +447,7 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
     shards = world if wide else 1
     # reference behaviour: every step reads the ps-resident variables (staleness 0); --staleness k pulls every (k+1)-th step
     staleness = args.staleness if getattr(args, "staleness", None) is not None else 0
+    bound = getattr(args, "staleness_bound", None)
     ds = mnist.synthetic_data_sets(train_size=train_rows, validation_size=100, test_size=100, seed=0 if not wide else rank)
     force = bool(getattr(args, "force_collectives", False)) and world == 1 and device.type == "cuda" and not wide
 
@@ -471,7 +472,7 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
                 os.environ.setdefault("MASTER_PORT", "29534")
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
             prog = program(fused=False, gs_inc=0)
-            engine = PeerMappedAsyncEngine(prog, state, 1, staleness=staleness)
+            engine = PeerMappedAsyncEngine(prog, state, 1, staleness=staleness, staleness_bound=bound)
             finish = engine.finish
         elif world == 1:
             # one worker and its own ps: every update is applied before the next gradient is computed
@@ -480,7 +481,7 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
             finish = lambda: None
         else:
             prog = program(fused=False, gs_inc=0)
-            engine = make_async_engine(prog, state, shards, staleness)
+            engine = make_async_engine(prog, state, shards, staleness, staleness_bound=bound)
             finish = engine.finish
         return state, prog, engine, finish
 
@@ -502,9 +503,10 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
         smax = int(_max_over_ranks(float(smax), device, world))
         smean = _max_over_ranks(smean, device, world)
         stale = (smax, smean)
-    forced = None
+    forced = waits = None
     if hasattr(engine, "forced_pulls"):
         forced = int(_max_over_ranks(float(engine.forced_pulls()), device, world))
+        waits = int(_max_over_ranks(float(engine.bound_waits()), device, world))
     finish()
     target = None
     if not wide and getattr(args, "target_loss", 0):
@@ -532,6 +534,8 @@ def bench_mlp_async(args, rank, world, device, wide: bool = False):
         out["staleness_bound"] = engine.staleness_bound
     if forced is not None:
         out["forced_pulls"] = forced
+    if waits is not None:
+        out["pushes_that_waited_for_a_slower_worker"] = waits
     if target is not None:
         out["target_loss"] = target["target_loss"]
         out["steps_to_target"] = target["steps_to_target"]

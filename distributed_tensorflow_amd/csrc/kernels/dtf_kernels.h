@@ -438,12 +438,16 @@ struct DtfAsyncPushPullArgs {
   int optimizer;          // 0 = SGD, 1 = Adam (moments m[], v[] next to the master slices)
   float* m[8];            // Adam moments of slice s in the (mapped) region of its owner
   float* v[8];
-  int* astate;            // optional local ints: [0] global_step at the last pull, [1] own pushes since
+  int* astate;            // optional local ints [8]: [0] global_step at the last pull, [1] own pushes since, [2] forced pulls,
+                          // [3] pushes that had to wait for a slower worker, [4] "pull with the next push", [5] bound given up
   int* alog;              // optional ring [alog_cap][2]: {global_step after the push, updates of OTHER workers the replica missed}
   int alog_cap;
   int pull_every;         // pull on local steps divisible by this (<= 1: every step); other steps push only
   float b1, b2, eps;
-  int pad_;
+  int bound;              // staleness bound (< 0: none): a replica that misses more than `bound` updates of other workers is
+                          // refreshed with the next push, and a worker more than `bound` steps ahead of the slowest waits
+  int rank, world;        // this worker and the number of workers (their step clocks sit at counters[0] + 4 + rank)
+  unsigned timeout_ticks; // limit of that wait in ticks of the 100 MHz constant clock
 };
 DTF_EXPORT int dtf_async_push_pull(const DtfAsyncPushPullArgs* a, hipStream_t s);
 DTF_EXPORT void* dtf_ipc_alloc(int64_t bytes, char* handle_out64);

@@ -493,7 +493,9 @@ __global__ __launch_bounds__(256) void async_push_pull_kernel(DtfAsyncPushPullAr
   const int64_t total4 = slice4 * a.shards;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int ls = a.state[1];                     // local step, already advanced by the step's tail
-  const bool do_pull = a.mode == 1 || a.pull_every <= 1 || (ls % a.pull_every) == 0;
+  // (the forced pull was decided by the previous push of this worker: one value for every workgroup of this launch)
+  const bool forced = a.astate && a.bound >= 0 && a.mode == 0 && a.astate[4] != 0;
+  const bool do_pull = a.mode == 1 || a.pull_every <= 1 || (ls % a.pull_every) == 0 || forced;
   int cur_s = -1;
   float lr_t = a.lr;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
@@ -549,6 +551,38 @@ __global__ __launch_bounds__(256) void async_push_pull_kernel(DtfAsyncPushPullAr
         }
         if (do_pull) { a.astate[0] = gs; a.astate[1] = 0; }
         else a.astate[1] += 1;
+        if (a.bound >= 0) {
+          // Bounded staleness (/root/reference/distributed.py:89, :102 has none: plain Hogwild).  (1) A replica that
+          // has fallen more than `bound` updates of other workers behind is refreshed with the next push, whatever
+          // the pull period says.  (2) Stale-synchronous clocks: every worker publishes the number of steps it has
+          // pushed; a worker more than `bound` steps ahead of the slowest waits here, i.e. before its next step
+          // starts.  A worker that has finished parks its clock at the maximum; a wait that runs into its limit (a
+          // worker died) gives the bound up for the rest of the run instead of stalling again at every step.
+          if (forced) a.astate[2] += 1;
+          a.astate[4] = (!do_pull && unseen >= (a.bound > 0 ? a.bound : 1)) ? 1 : 0;
+          int* clocks = a.counters[0] + 4;
+          __hip_atomic_store(clocks + a.rank, ls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (a.astate[5] == 0 && a.world > 1) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool waited = false;
+            for (;;) {
+              int slowest = 0x7fffffff;
+              for (int j = 0; j < a.world; ++j)
+                if (j != a.rank) slowest = min(slowest, __hip_atomic_load(clocks + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+              if (ls - slowest <= a.bound) break;
+              waited = true;
+              if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                a.astate[5] = 1;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(16);
+            }
+            if (waited) {
+              a.astate[3] += 1;
+              a.astate[4] = 1;                   // the others pushed while this worker waited: refresh with the next push
+            }
+          }
+        }
       }
     } else {
       gs = __hip_atomic_load(a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -564,6 +598,7 @@ DTF_EXPORT int dtf_async_push_pull(const DtfAsyncPushPullArgs* a, hipStream_t s)
   if (a->mode == 0 && !a->grads) return DTF_ERR_ARG;
   if (a->optimizer != 0 && a->optimizer != 1) return DTF_ERR_ARG;
   if (a->alog && !a->astate) return DTF_ERR_ARG;
+  if (a->bound >= 0 && (!a->astate || a->world < 1 || a->world > 8 || a->rank < 0 || a->rank >= a->world)) return DTF_ERR_ARG;
   for (int i = 0; i < a->shards; ++i) {
     if (!a->master[i] || !a->counters[i]) return DTF_ERR_ARG;
     if (a->optimizer == 1 && a->mode == 0 && (!a->m[i] || !a->v[i])) return DTF_ERR_ARG;

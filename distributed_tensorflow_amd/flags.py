@@ -211,6 +211,10 @@ def define_framework_flags(fv: FlagValues = FLAGS) -> None:
     DEFINE_integer('staleness', 0, 'Async mode: a worker pushes its gradient on every step and refreshes its replica from '
                    'the ps-resident parameters on every (staleness+1)-th; 0 = every step, as the reference (send/recv '
                    'engine: pulls that may still be in flight when the next step starts)', fv)
+    DEFINE_integer('staleness_bound', None, 'Async mode on the GPUs of one node: a replica that misses more than this many '
+                   'updates of OTHER workers is refreshed with the next push, and a worker more than this many steps ahead '
+                   'of the slowest waits for it (default: staleness + 2 x (workers - 1); negative: no bound, plain '
+                   'Hogwild as the reference runs it)', fv)
     DEFINE_integer('log_every', 1, 'Print the per-step line every N local steps (reference: every step)', fv)
     DEFINE_integer('steps_per_launch', 0, 'Steps replayed per hipGraph launch (0 = choose automatically)', fv)
     DEFINE_integer('validation_every', 10000, 'Validate every N local steps (reference: 10000, including step 0)', fv)

@@ -51,7 +51,7 @@ class AsyncPushPullArgs(C.Structure):
                 ("state", C.c_void_p), ("slice", C.c_int64), ("shards", C.c_int), ("mode", C.c_int), ("lr", C.c_float),
                 ("optimizer", C.c_int), ("m", C.c_void_p * 8), ("v", C.c_void_p * 8), ("astate", C.c_void_p),
                 ("alog", C.c_void_p), ("alog_cap", C.c_int), ("pull_every", C.c_int), ("b1", C.c_float), ("b2", C.c_float),
-                ("eps", C.c_float), ("pad_", C.c_int)]
+                ("eps", C.c_float), ("bound", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("timeout_ticks", C.c_uint)]
 
 
 _declared = False
@@ -95,7 +95,7 @@ class PeerMappedAsyncEngine:
     _instances = 0          # engines built so far in this process (the same on every rank): names the store keys
 
     def __init__(self, program, state: ShardedState, num_shards: int = 1, group=None, staleness: int = 0,
-                 log_capacity: int = 4096):
+                 log_capacity: int = 4096, staleness_bound: Optional[int] = None):
         if program.fused or program.gs_inc != 0:
             raise ValueError("async mode needs a program that stores gradients and leaves global_step to the ps")
         if state.device.type != "cuda":
@@ -113,9 +113,17 @@ class PeerMappedAsyncEngine:
         # A worker pulls every (staleness + 1)-th local step and pushes on every step; in between it applies its own
         # update to its replica.  0 = pull with every push.
         self.staleness = max(0, int(staleness))
+        # Bounded staleness (None: the default below; negative: none, plain Hogwild as the reference runs it).  A replica
+        # that misses more than the bound of OTHER workers' updates is refreshed with the next push, and a worker more
+        # than the bound in steps ahead of the slowest waits (stale-synchronous clocks next to global_step): a gradient
+        # is never applied more than bound + 2 x bound x (workers - 1) updates late.
+        if staleness_bound is None:
+            env = os.environ.get("DTF_STALENESS_BOUND")
+            staleness_bound = int(env) if env is not None else self.staleness + 2 * (self.world - 1)
+        self.staleness_bound = int(staleness_bound) if int(staleness_bound) >= 0 else None
         # per local step {global_step after the push, updates of other workers the replica had not seen}: device ring
         self.alog = torch.zeros((log_capacity, 2), dtype=torch.int32, device=self.device)
-        self._astate = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._astate = torch.zeros(8, dtype=torch.int32, device=self.device)
         PeerMappedAsyncEngine._instances += 1
         self._key = f"dtf/async_peer/{PeerMappedAsyncEngine._instances}"
         self.updates_pushed = 0
@@ -210,7 +218,12 @@ class PeerMappedAsyncEngine:
                 a.m[s] = self._base[s] + self.slice * 4
                 a.v[s] = self._base[s] + self.slice * 8
         a.grads, a.params, a.state = st.grads.data_ptr(), st.params.data_ptr(), st.state.data_ptr()
-        a.slice, a.shards, a.mode, a.lr, a.pad_ = self.slice, self.S, mode, float(lr), 0
+        a.slice, a.shards, a.mode, a.lr = self.slice, self.S, mode, float(lr)
+        a.bound = -1 if (check or self.staleness_bound is None) else self.staleness_bound
+        a.rank, a.world = self.rank, self.world
+        # how long a worker that is too far ahead waits for the slowest before it gives the bound up (a worker that
+        # died never advances its clock; one that finished parks it at the maximum)
+        a.timeout_ticks = int(min(4.0e9, float(os.environ.get("DTF_STALENESS_WAIT_S", "5")) * 1e8))
         a.optimizer = 1 if (self.adam and not check) else 0
         a.b1, a.b2, a.eps = st.beta1, st.beta2, st.eps
         if check:
@@ -302,13 +315,14 @@ class PeerMappedAsyncEngine:
             applied = int(st.state[2].item()) if self.adam else 0      # Adam's update count (restored from a checkpoint)
             self._counter_view()[0:2] = torch.tensor([st.global_step() if self.rank == 0 else 0, applied], dtype=torch.int32,
                                                       device=self.device)
+            self._counter_view()[4:12] = st.local_step()      # every worker's step clock starts where the counters stand
             mv = self.moment_views()
             if mv is not None:
                 lo = self.rank * self.slice
                 own = (lo, lo + self.slice) == tuple(st.shard) and st.m is not None
                 mv[0].copy_(st.m) if own else mv[0].zero_()
                 mv[1].copy_(st.v) if own else mv[1].zero_()
-        self._astate.copy_(torch.tensor([st.global_step(), 0], dtype=torch.int32))
+        self._astate.copy_(torch.tensor([st.global_step(), 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32))
         torch.cuda.synchronize(self.device)
         self._barrier()
 
@@ -344,6 +358,11 @@ class PeerMappedAsyncEngine:
         report keeps its slice allocated until the process ends (somebody may still be writing to it)."""
         import time
         torch.cuda.synchronize(self.device)
+        # this worker's step clock parks at the maximum: nobody waits for a worker that has left
+        if self.staleness_bound is not None and self._base and self._base[0]:
+            clocks = torch.as_tensor(_DevicePtr(self._base[0] + self._counter_off, COUNTER_BYTES // 4, "<i4"), device=self.device)
+            clocks[4 + self.rank] = 0x7fffffff
+            torch.cuda.synchronize(self.device)
         store = self._store()
         everyone = store is not None
         if store is not None:
@@ -381,6 +400,18 @@ class PeerMappedAsyncEngine:
         vals = log[idx, 1].to(torch.float64)
         return int(vals.max().item()), float(vals.mean().item())
 
+    def forced_pulls(self) -> int:
+        """Pushes of this worker that refreshed its replica because it had fallen behind the staleness bound."""
+        return int(self._astate[2].item())
+
+    def bound_waits(self) -> int:
+        """Pushes after which this worker waited for a slower one (it was more than the bound in steps ahead)."""
+        return int(self._astate[3].item())
+
+    def bound_given_up(self) -> bool:
+        """True once a wait for the slowest worker ran into the time limit (the run continues unbounded)."""
+        return int(self._astate[5].item()) != 0
+
     def _release(self, free_local: bool = True) -> None:
         lib = _lib_k()
         for p in self._mapped:
@@ -397,7 +428,7 @@ class PeerMappedAsyncEngine:
         return int(self._counter_view()[1].item()) if self.is_owner and self._local else 0
 
 
-def make_async_engine(program, state: ShardedState, num_shards: int, staleness: int, group=None):
+def make_async_engine(program, state: ShardedState, num_shards: int, staleness: int, group=None, staleness_bound=None):
     """The device-side engine where it applies (one node, SGD, GPUs, RCCL group), else the send/recv engine."""
     from .async_ps import AsyncParameterServerEngine
     import warnings
@@ -405,7 +436,7 @@ def make_async_engine(program, state: ShardedState, num_shards: int, staleness: 
             and state.layout.total % (4 * max(1, min(num_shards, state.world_size))) == 0
             and wanted(dist.get_backend(group), state.world_size) and _lib.kernels_available()):
         try:
-            return PeerMappedAsyncEngine(program, state, num_shards, group, staleness=staleness)
+            return PeerMappedAsyncEngine(program, state, num_shards, group, staleness=staleness, staleness_bound=staleness_bound)
         except PeerMappedUnavailable as e:                 # raised on every rank together
             warnings.warn(f"peer-mapped async engine unavailable ({e}); using send/recv")
     return AsyncParameterServerEngine(program, state, num_shards=num_shards, staleness=staleness)

@@ -283,7 +283,7 @@ def build_worker(role: Optional[Role], device: torch.device, datasets, hidden_un
                  learning_rate: float, sync_replicas: bool, replicas_to_aggregate: Optional[int], world: int, rank: int,
                  optimizer: str = "sgd", loss: str = "reference", post_update_accuracy: bool = True, hidden_layers: int = 1,
                  staleness: int = 0, num_ps: int = 1, seed: int = 0, collective: str = "auto", model: str = "mlp",
-                 dtype: str = "fp32"):
+                 dtype: str = "fp32", staleness_bound: Optional[int] = None):
     """Graph construction of distributed.py:60-102, as device-side state + step program + engine."""
     if model not in ("mlp", "wide_mlp"):
         raise ValueError(f"--model={model}: this script trains 'mlp' and 'wide_mlp' on MNIST-shape data "
@@ -313,7 +313,7 @@ def build_worker(role: Optional[Role], device: torch.device, datasets, hidden_un
         is_async = False
     else:
         prog = make_program(False, 0)
-        engine = make_async_engine(prog, state, num_ps, staleness)     # device-side push/pull where it applies
+        engine = make_async_engine(prog, state, num_ps, staleness, staleness_bound=staleness_bound)   # device-side push/pull where it applies
         is_async = True
     return state, prog, engine, is_async
 
@@ -361,7 +361,8 @@ def main(unused_argv=None) -> int:
         role, device, datasets, FLAGS.hidden_units, FLAGS.batch_size, FLAGS.learning_rate, FLAGS.sync_replicas,
         FLAGS.replicas_to_aggregate, num_workers, FLAGS.task_index, optimizer=FLAGS.optimizer, loss=FLAGS.loss,
         post_update_accuracy=FLAGS.post_update_accuracy, hidden_layers=FLAGS.hidden_layers, staleness=FLAGS.staleness,
-        num_ps=max(1, len(ps_spec)), seed=FLAGS.seed, model=FLAGS.model, dtype=FLAGS.dtype)
+        num_ps=max(1, len(ps_spec)), seed=FLAGS.seed, model=FLAGS.model, dtype=FLAGS.dtype,
+        staleness_bound=FLAGS.staleness_bound)
 
     sys.stderr.write("Worker %d: update engine %s\n" % (FLAGS.task_index, type(engine).__name__))   # not a reference line
     seed = FLAGS.seed if FLAGS.seed else (int(time.time() * 1000) & 0x7FFFFFFF)

@@ -779,3 +779,58 @@ def test_peer_async_worker_that_leaves_does_not_block_the_others():
     assert res[0]["applied"] == 2 * steps + 5
     assert res[0]["everyone"] is False and res[1]["everyone"] is False
     assert (res[0]["params"] == res[1]["params"]).all()
+
+
+def _peer_async_bound(rank, world, port, bound, steps):
+    """Rank 1 is the slow worker (it sleeps on the host between launches of four steps), rank 0 runs flat out."""
+    os.environ["DTF_PEER_ASYNC"] = "1"
+    import time
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.async_peer import make_async_engine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=100, test_size=300, seed=rank)
+    st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, lr=0.1)
+    st.initialize(seed=3)
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=rank), 100, [100], fused_update=False, gs_inc=0,
+                      post_update_accuracy=False)
+    eng = make_async_engine(prog, st, 1, 3, staleness_bound=bound)      # pull every fourth step unless forced
+    dist.barrier()
+    if rank == 1:
+        for _ in range(steps // 4):
+            eng.run(4, 4)
+            torch.cuda.synchronize()
+            time.sleep(0.01)
+    else:
+        eng.run(steps, 8)
+    torch.cuda.synchronize()
+    smax, smean = eng.staleness_stats(0, steps)
+    out = {"kind": type(eng).__name__, "smax": smax, "smean": smean, "forced": eng.forced_pulls(), "waits": eng.bound_waits(),
+           "gave_up": eng.bound_given_up(), "bound": eng.staleness_bound}
+    dist.barrier()
+    out["gs"] = eng.sync_params()
+    eng.finish(timeout_s=30.0)
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def test_peer_async_staleness_bound_is_enforced_on_the_device():
+    """Bound 3 with two workers, one of them slow: the fast worker waits on the device (its push kernel) whenever it is
+    more than three steps ahead, replicas that fell behind are refreshed ahead of their pull period, and no gradient is
+    applied more than bound + (workers - 1) x (2 x bound + 1) updates late.  Without a bound the slow worker's
+    gradients are as late as the fast worker is fast."""
+    world, steps, bound = 2, 64, 3
+    res = run_ranks(_peer_async_bound, world, bound, steps, timeout=200)
+    assert all(r["kind"] == "PeerMappedAsyncEngine" and r["bound"] == bound and not r["gave_up"] for r in res)
+    assert all(r["gs"] == 1 + world * steps for r in res)
+    limit = bound + (world - 1) * (2 * bound + 1)
+    assert all(r["smax"] <= limit for r in res), [r["smax"] for r in res]
+    assert res[0]["waits"] > 0                                          # the fast worker did wait for the slow one
+    assert res[0]["forced"] + res[1]["forced"] > 0
+    free = run_ranks(_peer_async_bound, world, -1, steps, timeout=200)
+    assert all(r["bound"] is None and r["waits"] == 0 and r["forced"] == 0 for r in free)
+    assert max(r["smax"] for r in free) > limit                         # plain Hogwild: nothing holds the fast worker back
