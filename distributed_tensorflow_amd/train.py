@@ -379,6 +379,21 @@ def main(unused_argv=None) -> int:
     sv.prepare_or_wait_for_session()                                                       # :125
     if hasattr(engine, "publish_state"):
         engine.publish_state()        # ps-resident copies of the variables are taken from the initialised state
+    if (FLAGS.sync_replicas and num_workers > 1 and getattr(engine, "p2p", None) is not None and getattr(engine, "fast", False)
+            and hasattr(engine, "select_transport")):
+        # Which peer-mapped transport is fastest depends on the node (link latency against link bandwidth against idle
+        # CUs): a short timed trial of each (collective; parameters and counters are put back), as bench.py does.
+        # DTF_P2P_MODE pins one and skips the trial.
+        import os
+        if os.environ.get("DTF_P2P_MODE") is None:
+            rec = engine.select_transport(192, 64, restore=True)
+            if rec is not None:
+                sys.stderr.write("Worker %d: sync transport '%s' after a trial of %d steps each (%s)\n" % (
+                    FLAGS.task_index, rec["chosen"], rec["steps_each"],
+                    ", ".join("%s %.1f us/step" % (k[:-len("_us_per_step")], v) for k, v in sorted(rec.items())
+                              if k.endswith("_us_per_step") and v is not None)))
+        else:
+            sys.stderr.write("Worker %d: sync transport '%s' (DTF_P2P_MODE)\n" % (FLAGS.task_index, engine.p2p_mode))
     print('Worker %d: Session initialization  complete.' % FLAGS.task_index)               # :126
 
     if FLAGS.sync_replicas and is_chief:

@@ -37,9 +37,11 @@ def test_overlapped_loop_prints_what_the_plain_loop_prints(extra, steps):
     assert any(l.startswith("Worker 0: test accuracy") for l in ahead)
 
 
-def test_two_sync_workers_sharing_the_gpu_print_the_same_with_both_loops():
+@pytest.mark.parametrize("transport", ["pipelined", "sharded"])
+def test_two_sync_workers_sharing_the_gpu_print_the_same_with_both_loops(transport):
     """1 ps + 2 workers as processes of the script, the workers on the one GPU of the box (gloo process group, peer-mapped
-    sync step): the loop that launches ahead prints what the plain loop prints, on both workers."""
+    sync step, the transport pinned so that both runs take the same one): the loop that launches ahead prints what the
+    plain loop prints, on both workers."""
     from dist_utils import free_port
 
     def run(mode):
@@ -47,7 +49,8 @@ def test_two_sync_workers_sharing_the_gpu_print_the_same_with_both_loops():
         common = ["--ps_hosts=127.0.0.1:%d" % ports[2], "--worker_hosts=127.0.0.1:%d,127.0.0.1:%d" % (ports[0], ports[1]),
                   "--sync_replicas", "--train_steps=1200", "--synthetic_data", "--synthetic_train_size=4000", "--learning_rate=0.5",
                   "--seed=7", "--validation_every=500", "--log_every=25", "--dist_backend=gloo"]
-        env = dict(os.environ, PYTHONUNBUFFERED="1", DTF_LOOP_OVERLAP=mode, DTF_SHARE_GPU="1", DTF_P2P_ALLREDUCE="1")
+        env = dict(os.environ, PYTHONUNBUFFERED="1", DTF_LOOP_OVERLAP=mode, DTF_SHARE_GPU="1", DTF_P2P_ALLREDUCE="1",
+                   DTF_P2P_MODE=transport)
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "distributed.py"), "--job_name=%s" % job, "--task_index=%d" % idx]
                                   + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
                  for job, idx in (("ps", 0), ("worker", 1), ("worker", 0))]
@@ -55,6 +58,8 @@ def test_two_sync_workers_sharing_the_gpu_print_the_same_with_both_loops():
         for p in procs:
             out, err = p.communicate(timeout=300)
             assert p.returncode == 0, err[-3000:]
+            if p is not procs[0]:
+                assert "sync transport '%s' (DTF_P2P_MODE)" % transport in err
             outs.append([l for l in out.splitlines() if not l.startswith("Training elapsed time") and "examples/sec" not in l])
         return outs[1], outs[2]
 
@@ -64,3 +69,31 @@ def test_two_sync_workers_sharing_the_gpu_print_the_same_with_both_loops():
     steps = [(int(m.group(1)), int(m.group(2))) for m in steps if m]
     assert steps and steps[-1][1] <= 1200 and all(a[0] < b[0] for a, b in zip(steps, steps[1:]))
     assert any(l.startswith("Worker 0: test accuracy") for l in w0_ahead)
+
+
+def test_sync_workers_time_the_transports_at_start_up_and_say_which_one_they_keep():
+    """Without a pinned transport the workers run a short trial of every peer-mapped transport before the first
+    training step (parameters and counters are put back: the step lines still start at 1) and name the winner."""
+    from dist_utils import free_port
+    ports = [free_port() for _ in range(3)]
+    common = ["--ps_hosts=127.0.0.1:%d" % ports[2], "--worker_hosts=127.0.0.1:%d,127.0.0.1:%d" % (ports[0], ports[1]),
+              "--sync_replicas", "--train_steps=300", "--synthetic_data", "--synthetic_train_size=4000", "--learning_rate=0.5",
+              "--seed=7", "--validation_every=500", "--dist_backend=gloo"]
+    env = {k: v for k, v in os.environ.items() if k != "DTF_P2P_MODE"}
+    env.update(PYTHONUNBUFFERED="1", DTF_SHARE_GPU="1", DTF_P2P_ALLREDUCE="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "distributed.py"), "--job_name=%s" % job, "--task_index=%d" % idx]
+                              + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+             for job, idx in (("ps", 0), ("worker", 1), ("worker", 0))]
+    res = [p.communicate(timeout=300) for p in procs]
+    for p, (_, err) in zip(procs, res):
+        assert p.returncode == 0, err[-3000:]
+    chosen = []
+    for out, err in res[1:]:
+        m = re.search(r"sync transport '(replicated|sharded|pipelined)' after a trial of 192 steps each \((.*)\)", err)
+        assert m, err[-2000:]
+        assert "pipelined" in m.group(2) and "sharded" in m.group(2) and "replicated" in m.group(2)
+        chosen.append(m.group(1))
+        steps = [STEP_RE.match(l.replace("Worker 1", "Worker 0")) for l in out.splitlines()]
+        steps = [(int(x.group(1)), int(x.group(2))) for x in steps if x]
+        assert steps[0] == (1, 1) and steps[-1][1] == 300
+    assert chosen[0] == chosen[1]
