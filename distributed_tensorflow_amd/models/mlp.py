@@ -449,6 +449,13 @@ class MLPProgram:
         elsewhere) means the next run starts with a prime launch.  Kernels write through raw pointers and leave the
         tensors' version counters alone."""
         st = self.state
+        if self.pipe_multi is not None and self.pipe_multi.world > 1:
+            # Several workers prime together or not at all (the prime launch is bracketed by barriers), so the decision
+            # may only rest on what every rank sees alike: parameters rewritten through the state's methods (initialise,
+            # restore, broadcast - every rank goes through them) and the number of steps.  An in-place edit of the flat
+            # tensors on one rank is not noticed here: the pipeline carries on from its working copies and the next
+            # flush overwrites the edit.
+            return (st.values_version, self.steps_enqueued)
         return (st.values_version, st.params._version, st.state._version, self.steps_enqueued)
 
     def _pipe_open(self) -> None:

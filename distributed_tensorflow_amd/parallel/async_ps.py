@@ -277,7 +277,9 @@ class AsyncParameterServerEngine:
 
     def publish_state(self) -> None:
         """After the chief has initialised or restored the variables: the owners take their counters (and Adam
-        moments) from the local state instead of starting from scratch."""
+        moments) from the local state instead of starting from scratch.  Collective: nobody returns - and so nobody
+        pushes - before every owner has taken its counters (a push that arrived earlier would be counted and then
+        overwritten)."""
         st = self.state
         with self._gs_lock:
             self._gs = st.global_step()
@@ -286,6 +288,8 @@ class AsyncParameterServerEngine:
         if self._m is not None and st.m is not None and (lo, hi) == tuple(st.shard):
             self._m.copy_(st.m)
             self._v.copy_(st.v)
+        if self.world > 1 and dist.is_initialized():
+            dist.barrier()
 
     def gather_moments(self):
         """Full flat Adam moments: this rank's own slice directly, the other owners' through a request on the pair

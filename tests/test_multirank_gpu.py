@@ -524,8 +524,8 @@ def _replica_fallback(rank, world, port):
     st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, lr=0.5)
     st.initialize(seed=3)
     prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=rank), 100, [100], fused_update=False)
-    eng = SyncReplicasEngine(prog, st, collective="all_reduce")
-    assert eng.p2p is not None and eng.p2p_fused
+    eng = SyncReplicasEngine(prog, st, collective="p2p_replicated")     # the exchange of gradient tiles inside the backward launch
+    assert eng.p2p is not None and eng.p2p_fused and eng.p2p_mode == "replicated"
     eng.run(6, 4)                                   # first run: replicas compared, equal
     torch.cuda.synchronize()
     # what a machine with a different ordering of peer traffic would produce: one replica off

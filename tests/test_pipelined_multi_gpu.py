@@ -205,3 +205,57 @@ def test_eight_ranks_sharing_the_gpu():
         assert out["digest"] == res[0]["digest"]
         for s in range(steps):
             assert abs(out["loss"][s] - losses[r][s]) < 3e-5, (r, s)
+
+
+def _diverging_replica(rank, world, port):
+    os.environ["DTF_P2P_ALLREDUCE"] = "1"
+    os.environ["DTF_SHARE_GPU"] = "1"
+    os.environ["DTF_P2P_TIMEOUT_S"] = "20"
+    import warnings
+    from distributed_tensorflow_amd.parallel.sync_replicas import SyncReplicasEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ds = mnist.synthetic_data_sets(train_size=2000, validation_size=100, test_size=100, seed=5)
+    st = build_mlp_state(784, [100], 10, dev, world_size=world, rank=rank, lr=0.5)
+    st.initialize(seed=3)
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=40 + rank), 100, [100], fused_update=False)
+    eng = SyncReplicasEngine(prog, st, collective="all_reduce")     # two workers: the pipelined exchange by default
+    first = eng.p2p_mode
+    eng.run(6, 4)
+    torch.cuda.synchronize()
+    if rank == 1:
+        st.params[5] += 1.0              # an edit of the flat tensor on one rank: not a reason to prime (see _pipe_token)
+    eng._replica_checks_left = 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        eng.run(6, 4)
+    torch.cuda.synchronize()
+    quiet = not any("replicas different" in str(x.message) for x in w)
+    same = float(st.params[5].item())
+    # what a machine that orders the peer traffic differently would leave behind: one rank's working copy off
+    if rank == 1:
+        prog.pbuf.wm[:, 5, 3] += 1.0
+    eng._replica_checks_left = 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        eng.run(6, 4)
+    torch.cuda.synchronize()
+    warned = any("pipelined exchange left the replicas different" in str(x.message) for x in w)
+    eng.run(8, 4)
+    torch.cuda.synchronize()
+    out = (st.params.cpu().numpy().copy(), first, quiet, same, warned, eng.p2p_mode, eng.p2p_fused, st.global_step(),
+           prog.pipe_multi is None)
+    dist.barrier()
+    eng.close_transports()
+    dist.destroy_process_group()
+    return out
+
+
+def test_one_rank_off_is_noticed_and_the_ranks_continue_on_the_update_launch():
+    a, b = run_ranks(_diverging_replica, 2, timeout=200)
+    for x in (a, b):
+        assert x[1] == "pipelined" and x[2]            # the flat-tensor edit neither primed one rank alone nor survived
+        assert x[4] and x[5] == "replicated" and not x[6] and x[8] and x[7] == 27
+    assert a[3] == b[3]
+    assert (a[0] == b[0]).all()

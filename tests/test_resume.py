@@ -123,8 +123,8 @@ def _async_resume_rank(rank, world, port, logdir):
         eng = AsyncParameterServerEngine(prog, st, num_shards=2, staleness=1)
         sv.engine = eng
         eng.publish_state()
-        out[f"gs_start{phase}"] = eng._gs
-        out[f"t_start{phase}"] = eng._adam_t
+        out[f"gs_start{phase}"] = st.global_step()            # (the engine's own counters move with the first push of a peer)
+        out[f"t_start{phase}"] = int(st.state[2].item())
         eng.run(10)
         eng.sync_params()                             # drains this worker's own pushes
         dist.barrier()                                # ... and now everybody's have been applied
