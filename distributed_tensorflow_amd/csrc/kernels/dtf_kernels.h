@@ -276,6 +276,8 @@ struct DtfPipeArgs {
   int roles;                // bit set of workgroup roles in this launch
   int flush;                // 1: role W writes W1 / b1 of the flat buffer
   int prime;                // 1: role Q also builds Z1 of the batch before the first step
+  int td;                   // tiles per side of the operand-layout matrices: 8 (Hd <= 127 and B <= 128) or 16 (Hd <= 256, B <= 256);
+                            // with 16 every "128" above reads 256, every "16384" 65536 and P2 holds 16 row blocks
   float lr, inv_b;
   DtfTailArgs tail;         // state, perm, n_train, gs_inc
 };

@@ -844,7 +844,7 @@ static int pm_validate(const DtfPipeMultiArgs* m) {
   if (m->world < 1 || m->world > PM_MAXR || m->rank < 0 || m->rank >= m->world) return DTF_ERR_ARG;
   for (int r = 0; r < m->world; ++r)
     if (!m->region[r] || ((uintptr_t)m->region[r] & 15)) return DTF_ERR_ARG;
-  if (a->In <= 0 || (a->In & 3) || a->Hd <= 0 || a->Hd > 127 || a->C <= 0 || a->C > 16 || a->B <= 0 || a->B > PIPE_ROWS)
+  if (a->In <= 0 || (a->In & 3) || a->Hd <= 0 || a->Hd > 127 || a->C <= 0 || a->C > 16 || a->B <= 0 || a->B > PIPE_ROWS || a->td != 8)
     return DTF_ERR_SHAPE;
   if (a->R != a->B && a->R != 2 * a->B) return DTF_ERR_SHAPE;
   if (a->HP != ((a->Hd + 1 + 15) & ~15) || a->KAp != ((a->In + 1 + 15) & ~15) || a->ldxa != a->KAp) return DTF_ERR_SHAPE;

@@ -103,19 +103,22 @@ class MLPProgram:
         in_dim = state.var(f"{self.names[0]}_w").shape[0]
         self.fused2 = (self.is_cuda and type(self)._supports_mlp2 and os.environ.get("DTF_FUSED_STEP", "1") != "0"
                        and ops.mlp2_eligible(in_dim, self.hidden, classes, batch))
-        if (self.is_cuda and type(self)._supports_mlp2 and not self.fused2 and os.environ.get("DTF_FUSED_STEP", "1") != "0"):
-            # a different code path, not just a different speed: say so once per program
-            import sys
-            sys.stderr.write(f"step program: {len(self.hidden)} hidden layer(s) of {self.hidden}, batch {batch}, {classes} classes "
-                             "is outside the two-launch step's range (one hidden layer <= 128 wide, batch <= 128, <= 16 "
-                             "classes): using the general three-launch sequence; multi-worker sync then aggregates through "
-                             "RCCL instead of the peer exchange inside the backward launch\n")
         # One worker with SGD in the step: the one-launch pipelined step (csrc/kernels/mlp_pipe.hip), whose dependent
         # path works on products with the weights of two steps ago plus Gram-matrix corrections; DTF_PIPELINED_STEP=0
         # keeps the two-launch step.
-        self.pipe = (self.fused2 and self.fused and os.environ.get("DTF_PIPELINED_STEP", "1") != "0"
+        self.pipe = (self.is_cuda and type(self)._supports_mlp2 and os.environ.get("DTF_FUSED_STEP", "1") != "0"
+                     and self.fused and os.environ.get("DTF_PIPELINED_STEP", "1") != "0"
                      and ops.pipe_eligible(in_dim, self.hidden, classes, batch)
                      and dataset.n >= 8 * batch)        # a launch looks three batches ahead within two epochs
+        if (self.is_cuda and type(self)._supports_mlp2 and not self.fused2 and not self.pipe
+                and os.environ.get("DTF_FUSED_STEP", "1") != "0"):
+            # a different code path, not just a different speed: say so once per program
+            import sys
+            sys.stderr.write(f"step program: {len(self.hidden)} hidden layer(s) of {self.hidden}, batch {batch}, {classes} classes "
+                             "is outside the range of the two-launch step (one hidden layer <= 128 wide, batch <= 128, <= 16 "
+                             "classes) and of the one-launch step (one worker, one hidden layer <= 256 wide, batch <= 256): "
+                             "using the general three-launch sequence; multi-worker sync then aggregates through "
+                             "RCCL instead of the peer exchange inside the backward launch\n")
         if self.pipe:
             self.fused2 = False
         # Per-step buffers rotate over P slots (slot of a step = local step % P).  P = 2: the tail of step s
@@ -125,7 +128,7 @@ class MLPProgram:
         self.P = ops._lib.PIPE_SLOTS if self.pipe else ops.MLP2_SLOTS if self.fused2 else 2
         self.ridx = torch.zeros((self.P, max(128, (2 * batch + 15) // 16 * 16)), dtype=i32, device=dev)
         if self.pipe:
-            self.pbuf = ops.PipeBuffers(in_dim, self.hidden[0], dev)
+            self.pbuf = ops.PipeBuffers(in_dim, self.hidden[0], dev, batch)
             self.wlog = torch.zeros((log_capacity, ops._lib.WLOG_INTS), dtype=i32, device=dev)
         if self.fused2:
             r16 = (self.R + 15) // 16
@@ -751,7 +754,7 @@ class MLPProgram:
             w = fetch()
         if not (self.fused2 or self.pipe):
             return w
-        nb = (self.R + 15) // 16
+        nb = min(16, (self.R + 15) // 16)           # 16 words per field of the record (loss parts, correct, post)
         loss = torch.zeros(w.shape[0], dtype=torch.float32)
         parts = w[:, 4:4 + nb].contiguous().view(torch.float32)
         for rb in range(nb):

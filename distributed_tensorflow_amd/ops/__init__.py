@@ -559,31 +559,43 @@ def mlp2_bwd(args):
     _lib.check(_lib.kernels().dtf_mlp2_bwd(C.byref(args), _lib.stream_handle()), "mlp2_bwd")
 
 
+def pipe_tiles(hd, batch) -> int:
+    """Tiles per side of the pipelined step's operand-layout matrices: 8 (the reference shape's class: hidden <= 127,
+    batch <= 128) or 16 (hidden <= 256, batch <= 256); ``pipe_td_of`` in ``csrc/kernels/mlp_pipe.hip``."""
+    return 8 if hd <= 127 and batch <= 128 else 16
+
+
 def pipe_eligible(in_dim, hidden, classes, batch) -> bool:
-    """Shapes the one-launch pipelined step of ``csrc/kernels/mlp_pipe.hip`` covers (the reference network does)."""
-    return (len(hidden) == 1 and hidden[0] <= 127 and classes <= 16 and batch <= 128 and in_dim % 4 == 0
-            and (in_dim + 16) // 16 + (batch + 15) // 16 <= 64)
+    """Shapes the one-launch pipelined step of ``csrc/kernels/mlp_pipe.hip`` covers: one hidden layer of at most 256
+    units, batches of at most 256 rows, at most 16 classes (--hidden_units / --batch_size of
+    /root/reference/distributed.py:11-13 are free integers; its defaults are 100 and 100)."""
+    if not (len(hidden) == 1 and hidden[0] <= 256 and classes <= 16 and batch <= 256 and in_dim % 4 == 0):
+        return False
+    chunks = 16 * (4 if pipe_tiles(hidden[0], batch) == 8 else 5)     # split-K of the Q products over 16 waves
+    return (in_dim + 16) // 16 + (batch + 15) // 16 <= chunks and (in_dim + 16) // 16 <= 64
 
 
 class PipeBuffers:
     """Working buffers of the pipelined step (two generations each, see ``DtfPipeArgs``)."""
 
-    def __init__(self, in_dim, hd, device):
+    def __init__(self, in_dim, hd, device, batch=128):
         f32, i32 = torch.float32, torch.int32
         self.HP = (hd + 1 + 15) // 16 * 16
         self.KAp = (in_dim + 1 + 15) // 16 * 16
+        self.td = td = pipe_tiles(hd, batch)
+        rows, mat = 16 * td, 256 * td * td
         z = lambda *shape: torch.zeros(shape, dtype=f32, device=device)
-        self.xa = z(_lib.PIPE_SLOTS, 128, self.KAp)
-        self.labg = z(_lib.PIPE_SLOTS, 16, 128)
+        self.xa = z(_lib.PIPE_SLOTS, rows, self.KAp)
+        self.labg = z(_lib.PIPE_SLOTS, 16, rows)
         self.wm = z(2, self.KAp, self.HP)
         self.w2m = z(2, self.HP, 16)
         # matrices that are only read as MFMA operands are stored per 16x16 tile in fragment order (mlp_pipe.hip)
-        self.q = z(2, 16384)
-        self.z1 = z(2, 16384)
-        self.labi = torch.zeros((_lib.PIPE_SLOTS, 128), dtype=i32, device=device)
-        self.gg = z(2, 3, 16384)
-        self.d1 = z(2, 16384)
-        self.p2 = z(2, 8, self.HP, 16)
+        self.q = z(2, mat)
+        self.z1 = z(2, mat)
+        self.labi = torch.zeros((_lib.PIPE_SLOTS, rows), dtype=i32, device=device)
+        self.gg = z(2, 3, mat)
+        self.d1 = z(2, mat)
+        self.p2 = z(2, td, self.HP, 16)
         self.ctr = torch.zeros((2, 2), dtype=i32, device=device)
 
 
@@ -604,8 +616,9 @@ def build_pipe_args(x, labels, bufs, ridx, w1, b1, w2, b2, wlog, batch, rows_tot
         raise ValueError("pipelined step: parameter shapes do not chain")
     if labels.shape[1] != c or labels.shape[0] != x.shape[0]:
         raise ValueError("pipelined step: labels do not match the dataset")
-    if bufs.HP != (hd + 1 + 15) // 16 * 16 or bufs.KAp != (in_dim + 1 + 15) // 16 * 16:
-        raise ValueError("pipelined step: working buffers were sized for another network")
+    if (bufs.HP != (hd + 1 + 15) // 16 * 16 or bufs.KAp != (in_dim + 1 + 15) // 16 * 16
+            or bufs.td != pipe_tiles(hd, batch)):
+        raise ValueError("pipelined step: working buffers were sized for another network or batch")
     if wlog.dim() != 2 or wlog.shape[1] != _lib.WLOG_INTS:
         raise ValueError("pipelined step: wide log must be [capacity, 64]")
     if ridx.dim() != 2 or ridx.shape[0] != _lib.PIPE_SLOTS or ridx.shape[1] < 2 * batch:
@@ -622,7 +635,7 @@ def build_pipe_args(x, labels, bufs, ridx, w1, b1, w2, b2, wlog, batch, rows_tot
                          W1=w1.data_ptr(), b1=b1.data_ptr(), W2=w2.data_ptr(), b2=b2.data_ptr(), wlog=wlog.data_ptr(),
                          In=in_dim, Hd=hd, C=c, B=batch, R=rows_total, HP=bufs.HP, KAp=bufs.KAp, ldxa=bufs.KAp,
                          ldx=x.stride(0), ridx_len=ridx.shape[1], q=slot, loss_mode=loss_mode, log_cap=wlog.shape[0],
-                         roles=roles, flush=int(flush), prime=int(prime), lr=float(lr), inv_b=1.0 / batch, tail=tail)
+                         roles=roles, flush=int(flush), prime=int(prime), td=bufs.td, lr=float(lr), inv_b=1.0 / batch, tail=tail)
 
 
 def pipe_step(args):
@@ -715,7 +728,7 @@ def build_pipem_args(x, labels, bufs, ridx, w1, b1, w2, b2, wlog, batch, rows_to
                          ctr=bufs.ctr.data_ptr(), W1=w1.data_ptr(), b1=b1.data_ptr(), W2=w2.data_ptr(), b2=b2.data_ptr(),
                          wlog=wlog.data_ptr(), In=in_dim, Hd=hd, C=c, B=batch, R=rows_total, HP=bufs.HP, KAp=bufs.KAp,
                          ldxa=bufs.KAp, ldx=x.stride(0), ridx_len=ridx.shape[2], q=slot, loss_mode=loss_mode,
-                         log_cap=wlog.shape[0], roles=roles, flush=int(flush), prime=int(prime), lr=float(lr_over_n),
+                         log_cap=wlog.shape[0], roles=roles, flush=int(flush), prime=int(prime), td=8, lr=float(lr_over_n),
                          inv_b=1.0 / batch, tail=tail)
     out = _lib.PipeMultiArgs(b=base, err=err.data_ptr(), rank=rank, world=world,
                              timeout_ticks=int(min(4.0e9, max(1.0, timeout_s * 1e8))), pad_=0)

@@ -152,7 +152,7 @@ class PipeArgs(C.Structure):
                 ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("wlog", C.c_void_p), ("In", C.c_int),
                 ("Hd", C.c_int), ("C", C.c_int), ("B", C.c_int), ("R", C.c_int), ("HP", C.c_int), ("KAp", C.c_int),
                 ("ldxa", C.c_int), ("ldx", C.c_int), ("ridx_len", C.c_int), ("q", C.c_int), ("loss_mode", C.c_int),
-                ("log_cap", C.c_int), ("roles", C.c_int), ("flush", C.c_int), ("prime", C.c_int), ("lr", C.c_float),
+                ("log_cap", C.c_int), ("roles", C.c_int), ("flush", C.c_int), ("prime", C.c_int), ("td", C.c_int), ("lr", C.c_float),
                 ("inv_b", C.c_float), ("tail", TailArgs)]
 
 

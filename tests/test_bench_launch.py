@@ -61,6 +61,16 @@ def test_bench_starts_its_own_two_gpu_workers_sharing_the_gpu(config):
     assert d["config"]["global_batch"] == 200
 
 
+@pytest.mark.gpu
+def test_bench_runs_the_one_launch_step_at_hidden_256_batch_256():
+    """--hidden_units / --batch_size are free integers in the reference (/root/reference/distributed.py:11-13): up to
+    256 / 256 one worker keeps the one-launch pipelined step."""
+    d = _one_json_line(_bench(["--steps", "40", "--warmup", "10", "--hidden_units", "256", "--batch_size", "256",
+                               "--target_loss", "0"]))
+    assert d["config"]["step_program"] == "one launch per step, pipelined (mlp_pipe.hip)"
+    assert d["config"]["global_batch"] == 256 and d["value"] > 0
+
+
 def test_bench_launcher_stops_its_workers_when_it_is_told_to_stop():
     """SIGTERM to the self-launching bench.py ends the worker processes it started (nothing is left behind for the
     next job on the machine)."""

@@ -87,7 +87,10 @@ def test_pipelined_step_eager_single_steps():
     _compare(_program(True, use_graphs=False), _program(False, use_graphs=False), steps=5, runs=(3, 2))
 
 
-@pytest.mark.parametrize("hidden,batch,classes,in_dim", [(31, 32, 5, 20), (127, 128, 16, 64), (64, 50, 10, 784), (100, 100, 10, 788)])
+@pytest.mark.parametrize("hidden,batch,classes,in_dim", [(31, 32, 5, 20), (127, 128, 16, 64), (64, 50, 10, 784), (100, 100, 10, 788),
+                                                         # the 16 x 16-tile geometry: hidden up to 256, batch up to 256
+                                                         (256, 256, 10, 784), (200, 128, 10, 784), (128, 100, 10, 784),
+                                                         (100, 200, 10, 784), (255, 250, 16, 100), (144, 60, 3, 36)])
 def test_pipelined_step_other_shapes(hidden, batch, classes, in_dim):
     _compare(_program(True, hidden=hidden, batch=batch, classes=classes, in_dim=in_dim, n_train=16 * batch),
              _program(False, hidden=hidden, batch=batch, classes=classes, in_dim=in_dim, n_train=16 * batch),

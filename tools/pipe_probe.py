@@ -2,6 +2,8 @@
 subsets of its workgroup roles (results of such launches are meaningless; only the time is read).
 
     python tools/pipe_probe.py [launches per graph] [repeats]
+
+PIPE_PROBE_HIDDEN / PIPE_PROBE_BATCH: another shape than the reference's 100 / 100.
 """
 import ctypes as C
 import os
@@ -27,9 +29,11 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     dev = torch.device("cuda", 0)
     ds = mnist.synthetic_data_sets(train_size=55000, validation_size=100, test_size=100, seed=0)
-    st = build_mlp_state(784, [100], 10, dev, lr=0.01)
+    hidden, batch = int(os.environ.get("PIPE_PROBE_HIDDEN", 100)), int(os.environ.get("PIPE_PROBE_BATCH", 100))
+    st = build_mlp_state(784, [hidden], 10, dev, lr=0.01)
     st.initialize(seed=1)
-    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=0), 100, [100])
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=0), batch, [hidden])
+    print(f"hidden {hidden}, batch {batch}")
     assert prog.pipe
     prog.run(16, 8)
     torch.cuda.synchronize()
