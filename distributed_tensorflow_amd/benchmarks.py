@@ -404,7 +404,15 @@ def bench_resnet50_sync(args, rank, world, device):
     autocast = torch.bfloat16 if dtype_name == "bf16" and device.type == "cuda" else None
     prog = TorchModuleProgram(model, device, images, labels, batch, world_size=world, rank=rank, optimizer=optimizer,
                               lr=1e-3 if optimizer == "adam" else 0.1, autocast=autocast)
-    engine = SyncReplicasEngine(prog, prog.state, collective=args.collective)
+    # --force_collectives on one GPU: the step the workers of a multi-GPU job run - gradients in buckets, per bucket
+    # reduce-scatter -> optimizer on the owned slice -> all-gather on a one-rank RCCL communicator
+    force = bool(getattr(args, "force_collectives", False)) and world == 1 and device.type == "cuda"
+    if force and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29535")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    engine = SyncReplicasEngine(prog, prog.state, collective="bucketed" if force else args.collective, force_collectives=force,
+                                capture_collectives=False if force else None)
     _sync_all(device, world)
     engine.run(args.warmup) if args.warmup > 0 else None
     _sync_all(device, world)
@@ -419,7 +427,8 @@ def bench_resnet50_sync(args, rank, world, device):
         "data": "synthetic ImageNet-shape (resident in HBM), random-init weights",
         "config": {"model": "ResNet-50", "global_batch": batch * world, "per_worker_batch": batch, "seq_len": None,
                    "parallelism": f"dp{world} sync_replicas, optimizer state sharded over {world} GPU(s)",
-                   "optimizer": optimizer, "mode": "sync", "collective": engine.collective if world > 1 else "none",
+                   "optimizer": optimizer, "mode": "sync", "collective": engine.collective if (world > 1 or force) else "none",
+                   "transport": engine.transport, "gradient_buckets": len(prog._groups) if prog._groups else None,
                    "params": prog.state.layout.used, "convolutions": "MIOpen (library)",
                    "classifier": ("own kernels (MFMA GEMM + fused softmax cross-entropy)"
                                   if head_calls["kernel"] and not head_calls["operators"]
@@ -427,7 +436,9 @@ def bench_resnet50_sync(args, rank, world, device):
                    "batch_norm": ("fused kernels (batchnorm.hip)" if bn_calls["kernel"] and not bn_calls["operators"]
                                   else "PyTorch operators" if not bn_calls["kernel"] else "mixed"),
                    "max_pool": "own kernels (maxpool.hip)" if pool_calls["kernel"] else "PyTorch operator",
-                   "gradients": ("handed over by autograd, multi-tensor copies into the flat buffer, bf16 weight copies"
+                   "gradients": (("handed over by autograd, one multi-tensor copy per bucket into the flat buffer on the "
+                                  "weight-gradient stream, bf16 weight copies" if prog._groups else
+                                  "handed over by autograd, multi-tensor copies into the flat buffer, bf16 weight copies")
                                  if prog._direct_now else "accumulated into views of the flat buffer")},
         "final_loss": last.loss,
     }

@@ -114,11 +114,11 @@ class _ConvWgradAside(torch.autograd.Function):
     ``w.grad`` here, on the side stream, and autograd gets None for ``w``."""
 
     @staticmethod
-    def forward(ctx, x, w, conv, side):
+    def forward(ctx, x, w, conv, side, stored=None):
         if x.dtype != w.dtype:
             x = x.to(w.dtype)                               # (what autocast does with the network's fp32 input)
         ctx.save_for_backward(x, w)
-        ctx.conv, ctx.side = conv, side
+        ctx.conv, ctx.side, ctx.stored = conv, side, stored
         return conv._conv_forward(x, w, None)
 
     @staticmethod
@@ -141,7 +141,9 @@ class _ConvWgradAside(torch.autograd.Function):
             x.record_stream(side)
         if ctx.needs_input_grad[0]:
             gx = torch.ops.aten.convolution_backward(gy, x, w, *args, [True, False, False])[0]
-        return gx, None, None, None
+        if gw is not None and ctx.stored is not None:
+            ctx.stored()                                    # the owner counts this gradient towards its bucket
+        return gx, None, None, None, None
 
 
 class TorchModuleProgram:
@@ -191,7 +193,7 @@ class TorchModuleProgram:
                 if isinstance(m, nn.Conv2d) and m.bias is None and m.padding_mode == "zeros":
                     w = torch.empty_like(m.weight, dtype=autocast, memory_format=fmt).requires_grad_(True)
                     self._copies[id(m.weight)] = w
-                    m.forward = self._conv_forward(m, w)
+                    m.forward = self._conv_forward(m, w, m.weight)
         # the batch counters of all batch-norm layers advance by one multi-tensor add per step, not one launch per layer
         self._bn_counters = []
         for m in self.module.modules():
@@ -229,13 +231,15 @@ class TorchModuleProgram:
         self._last_gs = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.gs_log = torch.zeros(log_capacity, dtype=torch.int32, device=self.device)
 
-    def _conv_forward(self, m: nn.Conv2d, w: torch.Tensor):
+    def _conv_forward(self, m: nn.Conv2d, w: torch.Tensor, master: torch.Tensor):
+        stored = lambda: self._count_gradient(master)
+
         def forward(x):
             # the compute copies are refreshed at the start of a training step only: any other forward pass
             # (evaluation, a pass after load_values or a restore) reads the master weights
             if self._direct_now and self.module.training and torch.is_grad_enabled() and self._in_step:
                 if self._side is not None:
-                    return _ConvWgradAside.apply(x, w, m, self._side)
+                    return _ConvWgradAside.apply(x, w, m, self._side, stored)
                 return m._conv_forward(x, w, None)
             return nn.Conv2d.forward(m, x)
         return forward
@@ -265,27 +269,77 @@ class TorchModuleProgram:
         """Gradient buckets (consecutive parameters, layout order) and the hooks that report them complete."""
         if self._groups is None:
             from ..parallel.bucketed import group_by_bytes
+            if os.environ.get("DTF_WGRAD_STREAM_BUCKETED", "0") != "1":
+                # With buckets the weight gradients stay on the main stream.  Measured on the ResNet-50 step at batch
+                # 256 with a one-rank communicator (library algorithm search off): 30.6 ms, against 32.6 ms with the
+                # second stream (a bucket's copy then queues behind every weight gradient that stream still has to
+                # run, and the bucket's collective behind the copy) and 31.0 ms with gradients accumulated into
+                # preassigned views; one worker without buckets: 29.6 ms with the second stream, 30.6 without.
+                self._side = None
             self._groups = group_by_bytes(self.state, self.bucket_bytes) if self.bucket_bytes else group_by_bytes(self.state)
             bucket_of = {n: i for i, g in enumerate(self._groups) for n in g}
             self._pending = [0] * len(self._groups)
             self._complete = [False] * len(self._groups)
             self._next = len(self._groups) - 1
+            self._bucket_of_param = {}
+            self._bucket_members = [[] for _ in self._groups]       # (parameter, its view of the flat gradient buffer)
+            views = {id(p): v for p, v in zip(self._params, self._grad_views)}
             for n, p in self.module.named_parameters():
-                p.register_post_accumulate_grad_hook(self._make_hook(bucket_of[n.replace(".", "/")]))
+                b = bucket_of[n.replace(".", "/")]
+                self._bucket_of_param[id(p)] = b
+                self._bucket_members[b].append((p, views[id(p)]))
+                if self.direct_grads and self._side is not None and id(p) in self._copies:
+                    # its gradient never passes through autograd's accumulation: the weight-gradient node of its
+                    # convolution stores it on the side stream and reports it (_count_gradient)
+                    continue
+                if self.direct_grads and id(p) in self._copies:
+                    self._copies[id(p)].register_post_accumulate_grad_hook(lambda _leaf, p=p: self._count_gradient(p))
+                else:
+                    p.register_post_accumulate_grad_hook(self._count_gradient)
         return self._groups
 
-    def _make_hook(self, b: int):
-        def hook(_param):
-            if self.grad_ready is None:
-                return
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._complete[b] = True
-                # release in descending order only: the collectives are issued in one order on every rank
-                while self._next >= 0 and self._complete[self._next]:
-                    self.grad_ready(self._next)
-                    self._next -= 1
-        return hook
+    def _count_gradient(self, param) -> None:
+        """One more gradient of the step exists (enqueued on the stream that computes it).  A bucket whose gradients
+        are all there is moved into the flat buffer (direct mode) and handed to the engine; buckets are released in
+        descending order only: the collectives are issued in one order on every rank."""
+        if self.grad_ready is None or self._groups is None:
+            return
+        b = self._bucket_of_param[id(param)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._complete[b] = True
+            while self._next >= 0 and self._complete[self._next]:
+                self._release_bucket(self._next)
+                self._next -= 1
+
+    def _release_bucket(self, b: int) -> None:
+        if not self._direct_now:
+            self.grad_ready(b)                              # the gradients were accumulated into the flat buffer's views
+            return
+        # Direct mode: the bucket's gradients are separate tensors - the convolutions' weight gradients computed on the
+        # side stream, everything else on the main stream.  One multi-tensor copy per source dtype moves them into the
+        # flat buffer ON THE SIDE STREAM (which first waits for the main stream's work enqueued so far), and the engine
+        # is told there: its collective stream then waits for that copy, while the main stream - batch-norm backward and
+        # data gradients of the layers below - never waits for a weight gradient.
+        main = torch.cuda.current_stream(self.device)
+        side = self._side if self._side is not None else main
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            by_dtype = {}
+            for p, view in self._bucket_members[b]:
+                g = self._copies.get(id(p), p).grad
+                if g is None:
+                    view.zero_()
+                    continue
+                if side is not main:
+                    g.record_stream(side)
+                dst, src = by_dtype.setdefault(g.dtype, ([], []))
+                dst.append(view)
+                src.append(g)
+            for dst, src in by_dtype.values():
+                torch._foreach_copy_(dst, src)
+            self.grad_ready(b)
 
     def enqueue_step(self) -> None:
         s = self.steps_enqueued
@@ -308,7 +362,8 @@ class TorchModuleProgram:
 
     def _step_body(self, x, y) -> None:
         """The device work of one step; touches no host state, so it can be captured and replayed."""
-        self._direct_now = direct = self.direct_grads and self.grad_ready is None and self._groups is None
+        # (gradient buckets registered but no engine listening: the hooks sit on the master parameters, keep their views)
+        self._direct_now = direct = self.direct_grads and (self.grad_ready is not None or self._groups is None)
         if direct:
             if self._copies:
                 leaves = list(self._copies.values())
@@ -329,8 +384,10 @@ class TorchModuleProgram:
             self._forward_backward(x, y)
         finally:
             self._in_step = False
-        if direct:
+        if direct and self.grad_ready is None:
             self._gradients_to_flat()
+        elif direct and self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)     # the last buckets' copies
         self._last_gs.copy_(self.state.state[0:1])
         if self.after_compute is not None:
             self.after_compute()

@@ -58,6 +58,10 @@ class WideMLPProgram(MLPProgram):
         self.refresh_compute_copies()
         self.grad_ready = None              # engine hook: called with a bucket index of grad_groups()
         self.folded = [False] * len(hidden)  # layers whose weight-gradient epilogue applies the optimizer itself
+        # bucketed aggregation: the engine's side stream rebuilds a layer's compute copies right behind the bucket's
+        # all-gather (use_side_refresh), so the next step starts without a pass over all the masters
+        self._run_behind = None
+        self._side_fresh = [False] * len(hidden)
         # weight-gradient products whose tiles would fill a fraction of the chip (first layer: 784 inputs) run split-K
         self.split_k = [None] * len(hidden)
         if self.is_cuda and T == torch.bfloat16 and os.environ.get("DTF_SPLIT_K", "1") != "0":
@@ -109,12 +113,22 @@ class WideMLPProgram(MLPProgram):
 
     def refresh_compute_copies(self, skip_folded: bool = False) -> None:
         """After an update of the fp32 master weights: rewrite W (compute dtype) and W^T."""
-        st = self.state
-        for l, name in enumerate(self.names):
-            if skip_folded and self.folded[l]:
-                continue                    # kept current by the weight-gradient epilogue of the previous step
-            master = st.var(f"{name}_w")
-            ops.gather_cast_transpose(master, None, self.w[l], self.w_t[l])
+        for l in range(len(self.names)):
+            if skip_folded and (self.folded[l] or self._side_fresh[l]):
+                continue                    # kept current by the weight-gradient epilogue / behind the bucket of the previous step
+            self._refresh_layer(l)
+
+    def _refresh_layer(self, l: int) -> None:
+        ops.gather_cast_transpose(self.state.var(f"{self.names[l]}_w"), None, self.w[l], self.w_t[l])
+
+    def use_side_refresh(self, run_behind) -> None:
+        """Bucketed aggregation (``parallel/bucketed.py``): ``run_behind(fn)`` enqueues fn on the engine's second
+        stream behind the buckets released so far and behind the compute stream's work so far.  The step then rebuilds
+        a layer's compute copies there, after the layer's all-gather and after the backward product that still reads
+        the old copy, instead of rebuilding every layer's copies at the start of the next step.
+        DTF_SIDE_REFRESH=0 keeps the pass at the start of the step."""
+        if self.is_cuda and self.cdtype != torch.float32 and os.environ.get("DTF_SIDE_REFRESH", "1") != "0":
+            self._run_behind = run_behind
 
     def enable_folded_optimizer(self):
         """One worker, bf16: the weight-gradient products that run on the 8-wave kernel apply the optimizer in their
@@ -210,6 +224,10 @@ class WideMLPProgram(MLPProgram):
                             mask_t=self.h_t[l - 1], out_t=self.dzc_t[l - 1], m=B)
             if self.grad_ready is not None and not early:
                 self.grad_ready(l)
+            if self.grad_ready is not None and self._run_behind is not None:
+                # W_l's last reader of this step has been enqueued: its copies may be rewritten once its bucket is back
+                self._run_behind(lambda l=l: self._refresh_layer(l))
+                self._side_fresh[l] = True
         if self.bf16_head:
             ops.out_wgrad_wide(self._args[q]["wgrad"])
         elif self.is_cuda:

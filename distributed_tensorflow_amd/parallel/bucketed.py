@@ -164,6 +164,19 @@ class BucketedUpdate:
         with torch.cuda.stream(self.side):
             self._process(i)
 
+    def run_behind(self, fn) -> None:
+        """Enqueue ``fn`` on the side stream, behind the buckets processed so far and behind everything the current
+        stream has enqueued so far (a consumer of a bucket's all-gather that must not start before a kernel of the
+        compute stream has read what it overwrites).  ``finish`` covers it like a bucket."""
+        if not self.cuda:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            fn()
+
     def finish(self) -> None:
         if not all(self._signalled):
             missing = [i for i, s in enumerate(self._signalled) if not s]

@@ -167,6 +167,8 @@ class SyncReplicasEngine:
         self.bucketed = BucketedUpdate(st, prog.grad_groups(), self.coll, 1.0 / self.R, native)
         prog.grad_ready = self.bucketed.ready
         prog.after_compute = self.bucketed.finish
+        if hasattr(prog, "use_side_refresh"):
+            prog.use_side_refresh(self.bucketed.run_behind)     # compute copies of the weights rebuilt behind each bucket
 
     def _install_native_update(self, group) -> None:
         """GPU fast path: aggregation + optimizer + redistribution become ONE entry of the native step
