@@ -204,10 +204,24 @@ struct DtfMlp2Shard {
 // kept as the local replica; the tail bumps the step counters with system-scope atomics.
 struct DtfMlp2Async {
   float* master[8];         // master slice of every shard (own shard: local pointer)
-  int* counters[8];         // per shard: [0] global_step (shard 0 only), [1] updates applied to this shard
+  int* counters[8];         // per shard: [0] global_step (shard 0 only), [1] updates applied to this shard, [4 + rank] step clocks (shard 0)
+  float* m[8];              // Adam: first / second moments next to every master slice (optimizer == 1)
+  float* v[8];
   const float* params_base; // start of the local flat parameter buffer (W1, b1, W2, b2 are views into it)
   long long slice;          // floats per shard
   int shards;
+  int optimizer;            // 0: SGD, 1: Adam with the owner-resident moments
+  int pull_every;           // the replica takes the master's values on local steps divisible by this (1: every step);
+                            // in between it takes this worker's own update only
+  int bound;                // bounded staleness as in DtfAsyncPushPullArgs (< 0: none); needs astate
+  int rank, world;
+  unsigned timeout_ticks;   // how long a worker that is too far ahead waits for the slowest
+  float b1, b2, eps;
+  int* astate;              // the 8 ints of DtfAsyncPushPullArgs.astate; [6], [7]: "the step with this parity pulls whatever
+                            // the period says", written one launch ahead (the launch that reads a slot never writes it)
+  int* alog;                // optional [alog_cap][2] ring: {global_step after the push, other workers' updates the replica missed}
+  int* applied_snap;        // Adam: [8] local ints, the slices' update counts as launch 1 of the step saw them
+  int alog_cap;
   int pad_;
 };
 

@@ -103,6 +103,12 @@ __global__ __launch_bounds__(1024) void mlp2_fwd_kernel(DtfMlp2Args p) {
     if (idx < Hd * C) { snap_idx = idx; snapv = p.W2[idx]; }
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) p.ctr_snap[threadIdx.x] = p.tail.state[threadIdx.x];
+  // asynchronous push with Adam: how many updates every slice has received, read once for the whole step (the tail
+  // of launch 2 advances the counters while the other workgroups of that launch are still computing their updates)
+  if (p.mode == 3 && p.async_.optimizer == 1 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x >= 64 &&
+      threadIdx.x < 64 + (unsigned)p.async_.shards)
+    p.async_.applied_snap[threadIdx.x - 64] =
+        __hip_atomic_load(p.async_.counters[threadIdx.x - 64] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
   M2_STAMP(0, blockIdx.y * gridDim.x + blockIdx.x);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -240,6 +246,24 @@ __device__ __forceinline__ void mlp2_stat_block(const DtfMlp2Args& p, int rb, in
   M2_STAMP(6, blockIdx.x);
 }
 
+// Asynchronous push inside the backward launch: does the step that makes `ls1` steps of this worker take the master's
+// values as its replica (the pull)?  The same answer in every workgroup of the launch: the forced-pull word of this
+// step's parity was written by the previous launch.
+__device__ __forceinline__ bool mlp2_async_pulls(const DtfMlp2Async& as, int ls1) {
+  if (as.pull_every <= 1 || (ls1 % as.pull_every) == 0) return true;
+  return as.bound >= 0 && as.astate && as.astate[6 + (ls1 & 1)] != 0;
+}
+
+// One element of the ps-resident Adam update (the arithmetic of async_push_pull_kernel): `applied` = updates the
+// element's slice had received when this worker looked.
+__device__ __forceinline__ float mlp2_async_adam(const DtfMlp2Async& as, float lr, float w, float g, float& m, float& v, int applied) {
+  const float t = (float)(applied + 1);
+  const float lr_t = lr * sqrtf(1.f - powf(as.b2, t)) / (1.f - powf(as.b1, t));
+  m = as.b1 * m + (1.f - as.b1) * g;
+  v = as.b2 * v + (1.f - as.b2) * (g * g);
+  return w - lr_t * m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + as.eps);
+}
+
 // Tail workgroup tb: counters (tb == 0) and rows [8*tb, 8*tb+8) of the next step's batch: 32 threads per row
 // copy the image row into the next Xg slot, the label row into the next labg slot, the index into ridx.
 template <int MODE>
@@ -258,10 +282,51 @@ __device__ __forceinline__ void mlp2_tail_block(const DtfMlp2Args& p, int tb) {
     rec[1] = ls;
     if (MODE == 3) {
       // the ps-side counters: global_step next to shard 0, one "updates applied" counter per shard
-      const int g2 = __hip_atomic_fetch_add(p.async_.counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
-      for (int s = 0; s < p.async_.shards; ++s)
-        __hip_atomic_fetch_add(p.async_.counters[s] + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const DtfMlp2Async& as = p.async_;
+      const int g2 = __hip_atomic_fetch_add(as.counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;
+      for (int s = 0; s < as.shards; ++s)
+        __hip_atomic_fetch_add(as.counters[s] + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       t.state[0] = g2;   // global_step as the ps holds it after this worker's update
+      if (as.astate) {
+        // the bookkeeping of async_push_pull_kernel (p2p_allreduce.hip), for the push inside this launch
+        const int ls1 = ls + 1;                          // steps of this worker including this one
+        const bool pulled = mlp2_async_pulls(as, ls1);
+        const int unseen = g2 - 1 - (as.astate[0] + as.astate[1]);
+        if (as.alog && as.alog_cap > 0) {
+          int* ar = as.alog + 2 * (size_t)(ls % as.alog_cap);
+          ar[0] = g2;
+          ar[1] = unseen < 0 ? 0 : unseen;
+        }
+        if (pulled) { as.astate[0] = g2; as.astate[1] = 0; }
+        else as.astate[1] += 1;
+        if (as.bound >= 0) {
+          if (as.astate[6 + (ls1 & 1)] != 0 && !(as.pull_every <= 1 || (ls1 % as.pull_every) == 0)) as.astate[2] += 1;
+          int force_next = (!pulled && unseen >= (as.bound > 0 ? as.bound : 1)) ? 1 : 0;
+          int* clocks = as.counters[0] + 4;
+          __hip_atomic_store(clocks + as.rank, ls1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (as.astate[5] == 0 && as.world > 1) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool waited = false;
+            for (;;) {
+              int slowest = 0x7fffffff;
+              for (int j = 0; j < as.world; ++j)
+                if (j != as.rank) slowest = min(slowest, __hip_atomic_load(clocks + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+              if (ls1 - slowest <= as.bound) break;
+              waited = true;
+              if (__builtin_amdgcn_s_memrealtime() - t0 > as.timeout_ticks) {
+                as.astate[5] = 1;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(16);
+            }
+            if (waited) {
+              as.astate[3] += 1;
+              force_next = 1;                            // the others pushed while this worker waited
+            }
+          }
+          as.astate[6 + ((ls1 + 1) & 1)] = force_next;   // read by the next launch; this launch reads the other slot
+        }
+      }
     } else {
       t.state[0] = gs + t.gs_inc;
     }
@@ -428,10 +493,15 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     for (int j = 0; j < NJ; ++j)
       wb[j] = bld(rw, (bn_ok && 4 * j + g < C) ? ((unsigned)(n0 + fr) * (unsigned)C + (unsigned)(4 * j + g)) * 4u : kOOB);
   }
+  // mode 3: where this lane's elements live in the masters (and, Adam, in the moments beside them).  The values are
+  // requested further down, once the operand loads above have been consumed: requested here, the uncached reads sat in
+  // front of them in the memory pipeline and every later stage of the workgroup started 2 us late.
   float* mptr[4] = {nullptr, nullptr, nullptr, nullptr};
   float* mbptr = nullptr;
+  long long moff[4] = {0, 0, 0, 0}, mboff = 0;
+  int msh[4] = {0, 0, 0, 0}, mbsh = 0;
+  bool a_pull = true;
   if (MODE == 3) {
-    // master values of this tile, requested now: the (possibly remote) read overlaps the whole launch
     const long long slice = p.async_.slice;
     const long long wbase = (long long)(Wt - p.async_.params_base), bbase = (long long)(bt - p.async_.params_base);
 #pragma unroll
@@ -439,14 +509,15 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
       const int row = m0 + 4 * g + r;
       const bool ok = row < Mo && bn_ok;
       const long long idx = ok ? wbase + (long long)row * N + n0 + fr : 0;
-      const int sh = p.async_.shards == 1 ? 0 : (int)(idx / slice);
-      mptr[r] = p.async_.master[sh] + (idx - (long long)sh * slice);
-      wold[r] = __builtin_nontemporal_load(mptr[r]);
+      msh[r] = p.async_.shards == 1 ? 0 : (int)(idx / slice);
+      moff[r] = idx - (long long)msh[r] * slice;
+      mptr[r] = p.async_.master[msh[r]] + moff[r];
     }
     const long long bidx = (mt == 0 && g == 0 && bn_ok) ? bbase + n0 + fr : 0;
-    const int bsh = p.async_.shards == 1 ? 0 : (int)(bidx / slice);
-    mbptr = p.async_.master[bsh] + (bidx - (long long)bsh * slice);
-    bold = __builtin_nontemporal_load(mbptr);
+    mbsh = p.async_.shards == 1 ? 0 : (int)(bidx / slice);
+    mboff = bidx - (long long)mbsh * slice;
+    mbptr = p.async_.master[mbsh] + mboff;
+    a_pull = mlp2_async_pulls(p.async_, p.ctr_snap[1] + 1);
   }
   int seq = 0;
   bool dead = false;                                // the transport has failed earlier in this run: do not wait again
@@ -457,7 +528,7 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
   }
   // mode 4: only the rank that owns this workgroup's tiles needs their old values
   const bool owner4 = MODE == 4 && (wgid % p.shard.world) == p.shard.rank;      // workgroup-uniform
-  if (MODE == 1 || MODE == 2 || owner4) {
+  if (MODE == 1 || MODE == 2 || MODE == 3 || owner4) {     // (mode 3: the replica's values, for a step that does not pull)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + 4 * g + r;
@@ -474,13 +545,34 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     for (int c = 0; c < CP; ++c) z[c] = sum8(za[c], zb[c]);
     mlp2_dz2_row<CP>(z, lab, C, tid < B, p.loss_mode, p.inv_b, dzs + tid * 20);
   }
+  // mode 3: the masters' values of this tile (uncached, possibly remote), requested here - behind every operand load in the
+  // memory pipeline, in front of the barrier: the read runs beside the barrier and the products below
+  float mw[4] = {0.f, 0.f, 0.f, 0.f}, mbw = 0.f, mm[4] = {0.f, 0.f, 0.f, 0.f}, mv[4] = {0.f, 0.f, 0.f, 0.f}, mbm = 0.f, mbv = 0.f;
+  int mt_cnt[4] = {0, 0, 0, 0}, mbt_cnt = 0;
+  if (MODE == 3 && has_tile) {
+    const DtfMlp2Async& as = p.async_;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mw[r] = __builtin_nontemporal_load(mptr[r]);
+    mbw = __builtin_nontemporal_load(mbptr);
+    if (as.optimizer == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        mm[r] = __builtin_nontemporal_load(as.m[msh[r]] + moff[r]);
+        mv[r] = __builtin_nontemporal_load(as.v[msh[r]] + moff[r]);
+        mt_cnt[r] = as.applied_snap[msh[r]];
+      }
+      mbm = __builtin_nontemporal_load(as.m[mbsh] + mboff);
+      mbv = __builtin_nontemporal_load(as.v[mbsh] + mboff);
+      mbt_cnt = as.applied_snap[mbsh];
+    }
+  }
+
   M2_STAMP(3, blockIdx.x);
   __syncthreads();
   M2_STAMP(4, blockIdx.x);
   // (mode 2: waves without a tile go on to the barriers of the exchange; their loads are out of range, i.e. zero,
   // and every store below is guarded)
   if (!has_tile && MODE != 2 && MODE != 4) return;
-
   // ---- the tile ----
   float bq[NRB][4];
   if (!IS2) {
@@ -751,9 +843,18 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
     if (row < Mo && bn_ok) {
       const size_t off = (size_t)row * N + n0 + fr;
       if (MODE == 3) {
-        const float w = wold[r] - p.lr * gv[r];
-        __builtin_nontemporal_store(w, mptr[r]);      // push: the master, wherever it lives
-        Wt[off] = w;                                   // pull: the same value is this worker's replica
+        // push: lock-free read-modify-write of the master, wherever it lives (and of the moments beside it)
+        float w;
+        if (p.async_.optimizer == 1) {
+          w = mlp2_async_adam(p.async_, p.lr, mw[r], gv[r], mm[r], mv[r], mt_cnt[r]);
+          __builtin_nontemporal_store(mm[r], p.async_.m[msh[r]] + moff[r]);
+          __builtin_nontemporal_store(mv[r], p.async_.v[msh[r]] + moff[r]);
+        } else {
+          w = mw[r] - p.lr * gv[r];
+        }
+        __builtin_nontemporal_store(w, mptr[r]);
+        // pull: the master's value is this worker's replica; between pulls the replica takes this worker's own update
+        Wt[off] = a_pull ? w : wold[r] + (w - mw[r]);
       } else if (MODE == 1) {
         Wt[off] = wold[r] - p.lr * gv[r];
       } else {
@@ -763,9 +864,16 @@ __device__ __forceinline__ void mlp2_train_block(const DtfMlp2Args& p, int tile0
   }
   if (b_lane) {
     if (MODE == 3) {
-      const float w = bold - p.lr * bsum;
+      float w;
+      if (p.async_.optimizer == 1) {
+        w = mlp2_async_adam(p.async_, p.lr, mbw, bsum, mbm, mbv, mbt_cnt);
+        __builtin_nontemporal_store(mbm, p.async_.m[mbsh] + mboff);
+        __builtin_nontemporal_store(mbv, p.async_.v[mbsh] + mboff);
+      } else {
+        w = mbw - p.lr * bsum;
+      }
       __builtin_nontemporal_store(w, mbptr);
-      bt[n0 + fr] = w;
+      bt[n0 + fr] = a_pull ? w : bold + (w - mbw);
     } else if (MODE == 1) {
       bt[n0 + fr] = bold - p.lr * bsum;
     } else {
@@ -818,8 +926,15 @@ static int mlp2_validate(const DtfMlp2Args* a) {
   if (a->mode == 3) {
     const DtfMlp2Async& as = a->async_;
     if (as.shards < 1 || as.shards > 8 || as.slice <= 0 || !as.params_base) return DTF_ERR_ARG;
-    for (int s = 0; s < as.shards; ++s)
+    if (as.optimizer != 0 && as.optimizer != 1) return DTF_ERR_ARG;
+    for (int s = 0; s < as.shards; ++s) {
       if (!as.master[s] || !as.counters[s]) return DTF_ERR_ARG;
+      if (as.optimizer == 1 && (!as.m[s] || !as.v[s])) return DTF_ERR_ARG;
+    }
+    if (as.optimizer == 1 && !as.applied_snap) return DTF_ERR_ARG;
+    if (as.optimizer == 1 && (!(as.b1 >= 0.f && as.b1 < 1.f) || !(as.b2 >= 0.f && as.b2 < 1.f) || !(as.eps > 0.f))) return DTF_ERR_ARG;
+    if (as.pull_every < 1 || (as.alog && !as.astate) || (as.alog && as.alog_cap <= 0)) return DTF_ERR_ARG;
+    if (as.bound >= 0 && (!as.astate || as.world < 1 || as.world > 8 || as.rank < 0 || as.rank >= as.world)) return DTF_ERR_ARG;
     // the four parameter tensors must be views into the flat buffer the slices partition
     const float* lo = as.params_base;
     const float* hi = lo + as.slice * as.shards;

@@ -120,8 +120,12 @@ class Mlp2Peer(C.Structure):
 
 class Mlp2Async(C.Structure):
     """Mirror of ``DtfMlp2Async``: mapped master slices and counters for the in-launch push/pull."""
-    _fields_ = [("master", C.c_void_p * 8), ("counters", C.c_void_p * 8), ("params_base", C.c_void_p),
-                ("slice", C.c_longlong), ("shards", C.c_int), ("pad_", C.c_int)]
+    _fields_ = [("master", C.c_void_p * 8), ("counters", C.c_void_p * 8), ("m", C.c_void_p * 8), ("v", C.c_void_p * 8),
+                ("params_base", C.c_void_p), ("slice", C.c_longlong), ("shards", C.c_int), ("optimizer", C.c_int),
+                ("pull_every", C.c_int), ("bound", C.c_int), ("rank", C.c_int), ("world", C.c_int),
+                ("timeout_ticks", C.c_uint), ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float),
+                ("astate", C.c_void_p), ("alog", C.c_void_p), ("applied_snap", C.c_void_p), ("alog_cap", C.c_int),
+                ("pad_", C.c_int)]
 
 
 class Mlp2Shard(C.Structure):

@@ -179,18 +179,25 @@ class PeerMappedAsyncEngine:
             raise PeerMappedUnavailable("the peer-mapped push/pull failed its start-up check on this machine")
         self.publish_state()
         entry = (OP_ASYNC_PUSH_PULL, self._push, 0)
-        # Opt-in (DTF_PEER_ASYNC_FUSED=1): the backward launch of the two-launch step pushes and pulls tile by tile,
-        # two launches per step.  Measured on one rank: the launch then ends 2.9 us later (it has to see its stores
-        # to the uncached master acknowledged), the separate push/pull kernel costs 3.9 us under the profiler and
-        # 3.0 us in the step: 14.8 us/step either way, so the simpler sequence stays the default.
-        self.fused = (bool(getattr(program, "fused2", False)) and os.environ.get("DTF_PEER_ASYNC_FUSED", "0") == "1"
-                      and self.staleness == 0 and not self.adam)
+        # The backward launch of the two-launch step pushes and pulls tile by tile (mode 3 of mlp2_fused.hip): two
+        # launches per step and no third kernel.  Every variant of the separate kernel is covered: a pull period,
+        # Adam with the owner-resident moments, the staleness log and bound.  DTF_PEER_ASYNC_FUSED=0 keeps the
+        # separate push/pull kernel behind the step's two launches.
+        self.fused = bool(getattr(program, "fused2", False)) and os.environ.get("DTF_PEER_ASYNC_FUSED", "1") != "0"
         if self.fused:
             a = _lib.Mlp2Async()
+            p = self._push
             for s in range(self.S):
                 a.master[s] = self._base[s]
                 a.counters[s] = self._base[s] + self._counter_off
+                if self.adam:
+                    a.m[s], a.v[s] = p.m[s], p.v[s]
             a.params_base, a.slice, a.shards, a.pad_ = state.params.data_ptr(), self.slice, self.S, 0
+            a.optimizer, a.pull_every, a.bound, a.rank, a.world = p.optimizer, p.pull_every, p.bound, p.rank, p.world
+            a.timeout_ticks, a.b1, a.b2, a.eps = p.timeout_ticks, p.b1, p.b2, p.eps
+            a.astate, a.alog, a.alog_cap = p.astate, p.alog, p.alog_cap
+            self._applied_snap = torch.zeros(8, dtype=torch.int32, device=self.device)
+            a.applied_snap = self._applied_snap.data_ptr()
             self._mlp2_async = a
             program.use_async_push(a, state.lr)
             program.after_compute = None

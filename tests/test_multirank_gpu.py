@@ -762,9 +762,55 @@ def _peer_async_v2(rank, world, port, shards, staleness, optimizer, steps, leave
     return out
 
 
-def test_peer_async_staleness_is_measured_on_the_device():
+def _one_rank_async(rank, world, port, optimizer, staleness, fused):
+    """One worker and its own ps shard through the mapped region: the arithmetic of a push is the same whether the
+    backward launch or the separate kernel applies it."""
+    os.environ["DTF_PEER_ASYNC_FUSED"] = fused
+    from distributed_tensorflow_amd.data import mnist
+    from distributed_tensorflow_amd.data.device_dataset import DeviceDataset
+    from distributed_tensorflow_amd.models.mlp import MLPProgram, build_mlp_state
+    from distributed_tensorflow_amd.parallel.async_peer import PeerMappedAsyncEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    dev = torch.device("cuda", 0)
+    ds = mnist.synthetic_data_sets(train_size=1000, validation_size=100, test_size=300, seed=0)
+    st = build_mlp_state(784, [100], 10, dev, lr=0.5 if optimizer == "sgd" else 0.01, optimizer=optimizer)
+    st.initialize(seed=3)
+    prog = MLPProgram(st, DeviceDataset(ds.train, dev, shuffle_seed=0), 100, [100], fused_update=False, gs_inc=0,
+                      post_update_accuracy=False)
+    eng = PeerMappedAsyncEngine(prog, st, 1, staleness=staleness)
+    eng.run(21, 8)
+    eng.step()
+    torch.cuda.synchronize()
+    before_pull = st.params.cpu().numpy().copy()
+    gs = eng.sync_params()
+    torch.cuda.synchronize()
+    out = {"fused": eng.fused, "gs": gs, "replica": before_pull, "params": st.params.cpu().numpy().copy(),
+           "loss": [r.loss for r in prog.read_log(0, 22)], "alog": eng.alog.cpu()[:22].tolist()}
+    eng.finish()
+    out["adam_t"] = int(st.state[2].item())
+    dist.destroy_process_group()
+    return out
+
+
+@pytest.mark.parametrize("optimizer,staleness", [("sgd", 0), ("sgd", 2), ("adam", 0), ("adam", 3)])
+def test_push_inside_the_backward_launch_equals_the_separate_kernel(optimizer, staleness):
+    (a,) = run_ranks(_one_rank_async, 1, optimizer, staleness, "1")
+    (b,) = run_ranks(_one_rank_async, 1, optimizer, staleness, "0")
+    assert a["fused"] and not b["fused"] and a["gs"] == b["gs"] == 23
+    assert a["alog"] == b["alog"] and a["adam_t"] == b["adam_t"]
+    assert a["loss"] == b["loss"]
+    assert (a["params"] == b["params"]).all()            # the master after 22 pushes
+    import numpy as np
+    # between pulls the replica follows the worker's own updates: the same values up to the rounding of w + (new - old)
+    np.testing.assert_allclose(a["replica"], b["replica"], rtol=1e-5, atol=1e-6)
+    assert a["loss"][-1] < a["loss"][0]
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_peer_async_staleness_is_measured_on_the_device(fused, monkeypatch):
     """staleness 2: a worker pushes every step and pulls every third; the kernel logs how many updates of the OTHER
     workers its replica had missed at each push."""
+    monkeypatch.setenv("DTF_PEER_ASYNC_FUSED", fused)
     world, steps = 3, 30
     res = run_ranks(_peer_async_v2, world, 1, 2, "sgd", steps)
     assert all(r["kind"] == "PeerMappedAsyncEngine" for r in res)
@@ -779,7 +825,9 @@ def test_peer_async_staleness_is_measured_on_the_device():
     assert max(r["smax"] for r in res) > 0                          # three workers do miss each other's updates
 
 
-def test_peer_async_adam_keeps_its_moments_with_the_owner():
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_peer_async_adam_keeps_its_moments_with_the_owner(fused, monkeypatch):
+    monkeypatch.setenv("DTF_PEER_ASYNC_FUSED", fused)
     world, steps = 2, 24
     res = run_ranks(_peer_async_v2, world, 2, 0, "adam", steps)
     assert all(r["kind"] == "PeerMappedAsyncEngine" for r in res)
