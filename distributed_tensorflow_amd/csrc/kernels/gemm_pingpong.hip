@@ -52,6 +52,16 @@ enum { REG_A0 = 0, REG_A1 = 1, REG_B0 = 2, REG_B1 = 3 };
 __device__ __forceinline__ unsigned short pp_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float pp_bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
+// Diagnostic build only (-DDTF_STAMPS): DTF_GEMM_SKIP_STORES = 1 / 2 / 3 leaves out the global stores of C / of the
+// transposed copy / of both in the forward and backward epilogues (everything else of the epilogue still runs): how
+// much of a launch the final burst of stores costs, i.e. the most that overlapping it with another tile's main loop
+// could win (tools/gemm_store_bound.sh).
+#ifdef DTF_STAMPS
+#define PP_DIAG_KEEP(bit) && !(p.pad_ & (bit))
+#else
+#define PP_DIAG_KEEP(bit)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 4 * 16384];   // [buffer][A0 A1 B0 B1][128 rows x 128 B]
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
       for (int it = 0; it < 16; ++it) {
         const int c = it * 4 + (lane >> 4), q = lane & 15;
         const u32x4 v = *reinterpret_cast<const u32x4*>(&wl[c * 256 + ((q ^ (c & 15)) << 4)]);
-        if (ccol + c < p.N && crow + q * 8 < p.M)
+        if (ccol + c < p.N && crow + q * 8 < p.M PP_DIAG_KEEP(2))
           *reinterpret_cast<u32x4*>(&Ct[(size_t)(ccol + c) * p.ldct + crow + q * 8]) = v;
       }
     }
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(DtfGemmArgs p) {
     for (int it = 0; it < 16; ++it) {
       const int R = it * 8 + (lane >> 3), q = lane & 7;
       const u32x4 v = *reinterpret_cast<const u32x4*>(&wl[R * 128 + (((q ^ (R >> 2)) & 7) << 4)]);
-      if (crow + R < p.M && ccol + q * 8 < p.N)
+      if (crow + R < p.M && ccol + q * 8 < p.N PP_DIAG_KEEP(1))
         *reinterpret_cast<u32x4*>(&C[(size_t)(crow + R) * p.ldc + ccol + q * 8]) = v;
     }
   }
@@ -466,8 +476,19 @@ bool dtf_gemm_pingpong_takes(const DtfGemmArgs& a) {
   return true;
 }
 
-int dtf_gemm_pingpong_launch(const DtfGemmArgs& a, hipStream_t s) {
-  if (!dtf_gemm_pingpong_takes(a)) return DTF_ERR_SHAPE;
+int dtf_gemm_pingpong_launch(const DtfGemmArgs& a_in, hipStream_t s) {
+  if (!dtf_gemm_pingpong_takes(a_in)) return DTF_ERR_SHAPE;
+#ifdef DTF_STAMPS
+  static int skip = -1;
+  if (skip < 0) {
+    const char* e = getenv("DTF_GEMM_SKIP_STORES");
+    skip = e ? atoi(e) & 3 : 0;
+  }
+  DtfGemmArgs a = a_in;
+  a.pad_ = skip;
+#else
+  const DtfGemmArgs& a = a_in;
+#endif
   const int split = a.ksplit > 1 ? a.ksplit : 1;
   dim3 grid(((a.M + 255) >> 8) * ((a.N + 255) >> 8) * split), block(512);
   switch (a.epilogue) {
