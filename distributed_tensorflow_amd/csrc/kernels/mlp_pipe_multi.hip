@@ -13,15 +13,21 @@
 // with G_rr'(a,b) = X'_r(a) X'_r'(b)^T.  Every rank holds the whole data set and every rank's shuffle, so it gathers
 // every worker's batches itself; what crosses xGMI per step and rank is D_r (B x H, 40 KB) and the rank's share of
 // the output layer's gradient (per 16-row block h'^T dz2: 7 x 4 KB) instead of the weight gradient (318 KB), in ONE
-// hop: a row workgroup stores its results straight into the boxes of every rank (own rank included) and raises one
-// flag per (source rank, row block) there; the row workgroups of the next launch wait for the flags of all sources.
+// hop: a row workgroup stores its results straight into the boxes of every rank (own rank included).  No flag and no
+// wait for an acknowledgement: every 32-bit word of a box carries its own arrival mark - the lowest mantissa bit is
+// overwritten with the PHASE of the step that wrote it, (step >> 2) & 1, which flips every time a box generation is
+// reused - so a reader requests the boxes of step s-1 together with its other operands, looks at the marks of what
+// came back and asks again only if a word still shows the phase of four steps ago.  (One round trip to uncached
+// memory on the dependent path of a step instead of three: store acknowledged -> flag -> flag seen -> boxes read.
+// Every rank reads the same bits, marks included, so the replicas stay bit-identical; the exchanged values lose their
+// last mantissa bit.)
 //
 // Only the row workgroups (14 per rank) ever wait.  The weight update and the Q products of launch s use D(s-2),
 // which every peer delivered before launch s-1 could end; so a rank's working copy of W1' lags two steps (one more
 // than with one worker) and the row workgroups apply two Gram corrections, the first of which (D(s-2)) needs nothing
-// of this launch and runs while the flags are still on their way.  Boxes rotate over four generations (step & 3): a
-// peer can be one launch ahead (it needs this rank's D(s) for more), and the update / Q roles of this rank's launch
-// s still read generation s-2 then.  Flags hold step stamps (local step + 1) that only grow, so "at least" is the test.
+// of this launch.  Boxes rotate over four generations (step & 3): a peer can be one launch ahead (it needs this
+// rank's D(s) for more), and the update / Q roles of this rank's launch s still read generation s-2 then.  (The last
+// 4 KB of a region, once flags, are unused.)
 //
 // Launch of step s, slot q = s mod 8, a = s & 1, p = 1 - a, boxes g0 = s & 3 (written), g1 = (s-1) & 3, g2 = (s-2) & 3:
 //   role L  row workgroups (training row blocks, then accuracy-only row blocks).  Waves 0..NT-1 own one 16-column
@@ -29,15 +35,16 @@
 //           (U(s) = U(s-1) - lrN sum over ranks and row blocks of the boxes' h'^T dz2) while the tile waves run the
 //           corrections.  The Gram strips of the row block (A operands, the same for every tile) are staged once per
 //           workgroup in LDS by LDS-DMA.  Reads Q[a] (accuracy-only rows: Z1[p]), GG[p], boxes g2 and g1, W2m[p];
-//           writes boxes g0 of EVERY rank + flags, Z1[a], W2m[a], the log record.
+//           writes boxes g0 of EVERY rank, Z1[a], W2m[a], the log record.
 //   role Q  Q[p] (for step s+1) = X'_r(s+1) Wm[p] - lrN sum_r' G_rr'(s+1,s-2) D_r'(s-2)
 //   role G  GG[a] = { G(s,s), G(s+1,s), G(s+1,s-1), G(s+2,s-1) } against every rank's batches: all read by launch s+1
 //   role W  Wm[a] = Wm[p] - lrN sum_r' X'_r'(s-2)^T D_r'(s-2)   (flush: both pending updates, into W1 / b1)
 //   role T  counters, log header; gather of every rank's batch of step s+3; row indices of step s+4
 //   role F  (flush) W2, b2 of the flat buffer; the flush launch runs behind a one-workgroup launch that waits for the
-//           last step's flags, so that no more than the row workgroups ever spin on a GPU that ranks share
-//   role C  (prime) working copies from the flat parameters, this rank's boxes zeroed, its flags set to the number of
-//           steps done; the host lets no rank start a step before every rank has primed
+//           last step's boxes, so that no more than the row workgroups ever spin on a GPU that ranks share
+//   role C  (prime) working copies from the flat parameters, this rank's boxes zeroed and marked (the generation the
+//           first step reads as "step before it": arrived; the others: not yet); the host lets no rank start a step
+//           before every rank has primed
 #include "mlp_pipe_common.h"
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
@@ -70,7 +77,6 @@ __device__ __forceinline__ float* pm_d1(char* region, int gen, int src) {
 __device__ __forceinline__ float* pm_p2(char* region, int gen, int src, int rb) {
   return reinterpret_cast<float*>(region + PM_P2_OFF) + (((size_t)gen * PM_MAXR + src) * 8 + rb) * PM_P2_BLK;
 }
-__device__ __forceinline__ int* pm_flags(char* region) { return reinterpret_cast<int*>(region + PM_FLAG_OFF); }
 __device__ __forceinline__ const float* pm_xa(const DtfPipeMultiArgs& m, int slot, int src) {
   return m.b.Xa + ((size_t)(slot & (PIPE_SLOTS - 1)) * m.world + src) * PIPE_ROWS * m.b.ldxa;
 }
@@ -123,33 +129,59 @@ __host__ __device__ __forceinline__ PmDims pm_dims(const DtfPipeMultiArgs& m, in
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// waiting for the boxes of one step: lane l watches flag l (source l >> 3, row block l & 7) of the local region
+// arrival marks: bit 0 of every word of a box = phase of the step that wrote it
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int pm_flag_peek(const DtfPipeMultiArgs& m, int nrb, int want, int lane) {
-  const bool watch = (lane >> 3) < m.world && (lane & 7) < nrb;      // nrb: row workgroups per rank of this launch shape
-  return watch ? __hip_atomic_load(pm_flags(m.region[m.rank]) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : want;
+__device__ __forceinline__ int pm_phase(int step) { return (step >> 2) & 1; }      // (arithmetic shift: step -1 has phase 1)
+__device__ __forceinline__ float pm_mark(float v, int phase) {
+  return __uint_as_float((__float_as_uint(v) & ~1u) | (unsigned)phase);
 }
-// `seen`: what pm_flag_peek returned earlier (the first look is issued with the wave's other loads)
-__device__ __forceinline__ void pm_flag_wait(const DtfPipeMultiArgs& m, int nrb, int want, int lane, int seen) {
-  if (__builtin_amdgcn_ballot_w64(seen - want < 0) != 0) {
-    const bool dead = __hip_atomic_load(m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-      seen = pm_flag_peek(m, nrb, want, lane);
-      if (__builtin_amdgcn_ballot_w64(seen - want < 0) == 0) break;
-      // (one decision per wave: every lane looks at the same clock reading)
-      const unsigned long long now = __builtin_amdgcn_readfirstlane((unsigned)(__builtin_amdgcn_s_memrealtime() - t0));
-      if (dead || now > m.timeout_ticks) {
-        if (lane == 0) __hip_atomic_store(m.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;                                         // the step goes on with what is there; the host sees the word
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
+// 0 if the four words carry `phase`
+__device__ __forceinline__ unsigned pm_stale4(const float (&v)[4], int phase) {
+  const unsigned all_or = __float_as_uint(v[0]) | __float_as_uint(v[1]) | __float_as_uint(v[2]) | __float_as_uint(v[3]);
+  const unsigned all_and = __float_as_uint(v[0]) & __float_as_uint(v[1]) & __float_as_uint(v[2]) & __float_as_uint(v[3]);
+  return phase ? (~all_and & 1u) : (all_or & 1u);
+}
+// what the prime launch leaves in a box word of generation `gen` when the first step of the run is step `first`
+__device__ __forceinline__ float pm_prime_word(int first, int gen) {
+  const int before = first - 1;
+  if (gen == (before & 3)) return __uint_as_float((unsigned)pm_phase(before));
+  const int next_writer = first + ((gen - first) & 3);
+  return __uint_as_float((unsigned)(pm_phase(next_writer) ^ 1));
+}
+// One decision per wave after a look at `stale` (words that do not show the phase yet, per lane): PM_ARRIVED, PM_AGAIN
+// (after a short sleep), or PM_GAVE_UP after the time limit (or at once when the transport has failed earlier in the
+// run): the step then goes on with what is there and the host sees the error word.
+enum { PM_ARRIVED = 0, PM_AGAIN = 1, PM_GAVE_UP = 2 };
+struct PmPoll {
+  unsigned long long t0;
+  bool started, dead;
+};
+__device__ __forceinline__ int pm_poll(const DtfPipeMultiArgs& m, PmPoll& st, unsigned stale, int lane) {
+  if (__builtin_amdgcn_ballot_w64(stale != 0) == 0) return PM_ARRIVED;
+  if (!st.started) {
+    st.started = true;
+    st.dead = __hip_atomic_load(m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    st.t0 = __builtin_amdgcn_s_memrealtime();
   }
-  // The boxes are read after the flags: the flag values have returned (they were just compared), the box loads are
-  // issued behind this line and go to memory (pm_bld4_sys); nothing for the compiler to move across it.
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long now = __builtin_amdgcn_readfirstlane((unsigned)(__builtin_amdgcn_s_memrealtime() - st.t0));
+  if (st.dead || now > m.timeout_ticks) {
+    if (lane == 0) __hip_atomic_store(m.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return PM_GAVE_UP;
+  }
+  __builtin_amdgcn_s_sleep(2);
+  return PM_AGAIN;
+}
+// Waiting is done on ONE 1 KB piece (16 bytes per lane at `voff` + `soff` of `r`): a wave that asked again for all of
+// its operands in a loop would keep tens of kilobytes of uncached reads in flight per look, times every wave of every
+// row workgroup - traffic the peers it is waiting for have to compete with when ranks share a GPU.
+__device__ __forceinline__ int pm_wait_piece(const DtfPipeMultiArgs& m, PmPoll& st, rsrc_t r, unsigned voff, unsigned soff, int phase,
+                                             int lane) {
+  for (;;) {
+    float v[4];
+    pm_bld4_sys(r, voff, soff, v);
+    const int rc = pm_poll(m, st, pm_stale4(v, phase), lane);
+    if (rc != PM_AGAIN) return rc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -166,6 +198,33 @@ __device__ __forceinline__ void pm_load_d(const DtfPipeMultiArgs& m, int gen, in
     const rsrc_t rd = make_rsrc(pm_d1(m.region[m.rank], gen, on ? src : 0), PIPE_MAT * 4u);
 #pragma unroll
     for (int jb = 0; jb < NRB; ++jb) pm_bld4_sys(rd, on ? pipe_frag(tile, jb, lane) * 4u : kOOB, 0, db[u][jb]);
+  }
+}
+// index (u * NRB + jb, wave-uniform) of the first loaded tile with a word that does not show `phase`, or -1
+template <int NRB>
+__device__ __forceinline__ int pm_first_stale(const DtfPipeMultiArgs& m, int s0, int phase, const float (&db)[2][NRB][4]) {
+  int bad = -1;
+#pragma unroll
+  for (int u = 1; u >= 0; --u) {
+    if (s0 + u >= m.world) continue;
+#pragma unroll
+    for (int jb = NRB - 1; jb >= 0; --jb)
+      if (__builtin_amdgcn_ballot_w64(pm_stale4(db[u][jb], phase) != 0) != 0) bad = u * NRB + jb;
+  }
+  return bad;
+}
+// the D tiles of one step that may still be on their way: what the request brought is looked at; while a tile is
+// incomplete the wave waits on that tile alone and then asks for everything again
+template <int NRB>
+__device__ __forceinline__ void pm_await_d(const DtfPipeMultiArgs& m, int gen, int s0, int tile, int lane, int phase, PmPoll& st,
+                                           float (&db)[2][NRB][4]) {
+  for (;;) {
+    const int bad = pm_first_stale<NRB>(m, s0, phase, db);
+    if (bad < 0) return;
+    const int u = bad / NRB, jb = bad - u * NRB;
+    const rsrc_t rd = make_rsrc(pm_d1(m.region[m.rank], gen, s0 + u), PIPE_MAT * 4u);
+    if (pm_wait_piece(m, st, rd, pipe_frag(tile, jb, lane) * 4u, 0, phase, lane) == PM_GAVE_UP) return;
+    pm_load_d<NRB>(m, gen, s0, tile, true, lane, db);
   }
 }
 // acc += strip(kind slot kk, source) . D tiles, A operands from the LDS strips
@@ -231,17 +290,16 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
     lds_byte_t* dst = (lds_byte_t*)(strips) + (size_t)t * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rgs, dst, 16, (int)(pipe_frag(rb, jb, lane) * 4u), 0, 0, 0);
   }
-  // ---- the step counter and a first look at the flags (the stamps of step s-1 are the step counter of this step),
-  //      then every load that does not depend on the flags ----
+  // ---- the step counter, then every operand of the wave in one go: a tile wave asks for the boxes of step s-1
+  //      right away (first two sources; they carry their own arrival marks), its output-layer wave for those of
+  //      step s-2, whose correction it runs ----
   const rsrc_t rctr = make_rsrc(p.ctr, 16u);
   const int ls = bldi(rctr, (unsigned)(2 * a + 1) * 4u);
-  const bool waits = t_wave || o_wave;
-  int seen = 0;
-  if (waits) seen = pm_flag_peek(m, NRB, ls, lane);
   const rsrc_t rq = make_rsrc(post ? p.Z1 + (size_t)pg * PIPE_MAT : p.Q + (size_t)a * PIPE_MAT, PIPE_MAT * 4u);
   float qv[4], db[2][NRB][4];
   bld4(rq, t_wave ? pipe_frag(rb, tile, lane) * 4u : kOOB, qv);
-  pm_load_d<NRB>(m, g2, 0, tile, o_wave && !post, lane, db);       // (the output-layer wave of the tile runs the D(s-2) term)
+  if (t_wave) pm_load_d<NRB>(m, g1, 0, tile, true, lane, db);
+  else pm_load_d<NRB>(m, g2, 0, tile, o_wave && !post, lane, db);
   const int srow = tid >> 4;                          // threads [0,256): row srow, class fr
   const int lslot = post ? ((p.q + PIPE_SLOTS - 1) & (PIPE_SLOTS - 1)) : p.q;
   const rsrc_t rlab = make_rsrc(p.labg + lslot * PIPE_LABG_SLOT, PIPE_LABG_SLOT * 4u);
@@ -253,9 +311,6 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
   float w2o[4];
   bld4(rw2, o_wave ? (unsigned)(tile * 64 + lane) * 16u : kOOB, w2o);
   __builtin_amdgcn_sched_barrier(0);
-  // (Asking for the boxes of step s-1 right here when the first look finds every flag set was tried: the barrier
-  // below then waits for that second round trip to uncached memory too, the D(s-2) term starts later and the row
-  // workgroup ends 0.8 us later, not earlier.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                     // the strips are in LDS
   PM_STAMP(1);
@@ -274,31 +329,50 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
     for (int r = 0; r < 4; ++r) acca[tile][r][lane] = acc0[r] + acc1[r];
   }
   PM_STAMP(2);
-  // ---- the boxes of step s-1 ----
-  if (waits) pm_flag_wait(m, NRB, ls, lane, seen);
-  PM_STAMP(3);
+  // ---- the boxes of step s-1: what came back with the first request is looked at; words that still show the phase
+  //      of four steps ago are asked for again ----
+  PmPoll poll = {0ull, false, false};
+  const int ph1 = pm_phase(ls - 1);
   if (t_wave) {
     // correction for D(s-1) (accuracy-only rows: the only one)
     const int kk = post ? 0 : 1;
     for (int s0 = 0; s0 < world; s0 += 2) {
-      pm_load_d<NRB>(m, g1, s0, tile, true, lane, db);
+      if (s0 > 0) pm_load_d<NRB>(m, g1, s0, tile, true, lane, db);
+      pm_await_d<NRB>(m, g1, s0, tile, lane, ph1, poll, db);
       pm_correct<NRB>(m, strips, kk, s0, lane, db, acc0, acc1);
     }
   }
+  PM_STAMP(3);
   float hreg[4] = {0.f, 0.f, 0.f, 0.f};
   float zv[4] = {0.f, 0.f, 0.f, 0.f};
   if (o_wave) {
-    // U(s) rows n0 + 4g + j, class fr: U(s-1) minus lrN times every rank's, every row block's share, in rank order
+    // U(s) rows n0 + 4g + j, class fr: U(s-1) minus lrN times every rank's, every row block's share, in rank order;
+    // two sources per request
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int src = 0; src < world; ++src) {
-      const rsrc_t rp2 = make_rsrc(pm_p2(mine, g1, src, 0), 8u * PM_P2_BLK * 4u);
-      float part[NRB][4];
+    for (int s0 = 0; s0 < world; s0 += 2) {
+      for (;;) {
 #pragma unroll
-      for (int k = 0; k < NRB; ++k) pm_bld4_sys(rp2, (unsigned)(tile * 64 + lane) * 16u, (unsigned)k * PM_P2_BLK * 4u, part[k]);
+        for (int u = 0; u < 2; ++u) {
+          const bool on = s0 + u < world;
+          const rsrc_t rp2 = make_rsrc(pm_p2(mine, g1, on ? s0 + u : 0, 0), 8u * PM_P2_BLK * 4u);
 #pragma unroll
-      for (int k = 0; k < NRB; ++k)
+          for (int k = 0; k < NRB; ++k)
+            pm_bld4_sys(rp2, on ? (unsigned)(tile * 64 + lane) * 16u : kOOB, (unsigned)k * PM_P2_BLK * 4u, db[u][k]);
+        }
+        const int bad = pm_first_stale<NRB>(m, s0, ph1, db);
+        if (bad < 0) break;
+        const int u = bad / NRB, k = bad - u * NRB;
+        const rsrc_t rp2 = make_rsrc(pm_p2(mine, g1, s0 + u, 0), 8u * PM_P2_BLK * 4u);
+        if (pm_wait_piece(m, poll, rp2, (unsigned)(tile * 64 + lane) * 16u, (unsigned)k * PM_P2_BLK * 4u, ph1, lane) == PM_GAVE_UP) break;
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sum[j] += part[k][j];
+      for (int u = 0; u < 2; ++u)
+        if (s0 + u < world) {
+#pragma unroll
+          for (int k = 0; k < NRB; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum[j] += db[u][k][j];
+        }
     }
     float w2v[4];
 #pragma unroll
@@ -409,8 +483,14 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
 #pragma unroll
     for (int r = 0; r < 4; ++r) u4[r] = u0[r] + u1[r];
   }
-  // ---- the exchange: both results into the boxes of EVERY rank (the same order of bytes everywhere), then one flag
-  //      per destination once every store of the workgroup has been acknowledged ----
+  // ---- the exchange: both results, every word marked with this step's phase, into the boxes of EVERY rank (the
+  //      same bytes everywhere); nothing waits for the stores ----
+  const int phw = pm_phase(ls);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    d4[r] = pm_mark(d4[r], phw);
+    u4[r] = pm_mark(u4[r], phw);
+  }
 #pragma unroll
   for (int d = 0; d < PM_MAXR; ++d) {
     if (d < world) {
@@ -420,10 +500,6 @@ __device__ __forceinline__ void pm_role_l(const DtfPipeMultiArgs& m, int rbl, fl
       pm_store4_sys(rpd, (unsigned)(tile * 64 + lane) * 16u, u4);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                     // (the waves that are left: the tile waves)
-  if (wave == 0 && lane < world)
-    __hip_atomic_store(pm_flags(m.region[lane]) + m.rank * 8 + rb, ls + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   PM_STAMP(7);
 }
 
@@ -782,21 +858,22 @@ __device__ __forceinline__ void pm_role_c(const DtfPipeMultiArgs& m, int cb) {
     // boxes of source rank `src`: every generation of D, then every generation of the output-layer shares
     const int src = (int)(e / (nBoxD + nBoxP));
     const long long r = e - (long long)src * (nBoxD + nBoxP);
+    // zero, marked: the generation the first step reads as "the step before it" has arrived (no pending update from
+    // anybody), every other generation shows the opposite of the phase its next writer will bring
+    const int first = p.tail.state[1];
     if (r < nBoxD) {
       const int gen = (int)(r / PIPE_MAT);
-      pm_d1(mine, gen, src)[r - (long long)gen * PIPE_MAT] = 0.f;
+      pm_d1(mine, gen, src)[r - (long long)gen * PIPE_MAT] = pm_prime_word(first, gen);
     } else {
       const long long rr = r - nBoxD;
       const int gen = (int)(rr / (8 * PM_P2_BLK));
-      pm_p2(mine, gen, src, 0)[rr - (long long)gen * 8 * PM_P2_BLK] = 0.f;
+      pm_p2(mine, gen, src, 0)[rr - (long long)gen * 8 * PM_P2_BLK] = pm_prime_word(first, gen);
     }
   }
   if (cb == 0 && threadIdx.x < 2) {
     // p.q is the slot of the launch BEFORE the first step: that step reads generation (q + 1) & 1 of the counters
     p.ctr[2 * ((p.q & 1) ^ 1) + threadIdx.x] = p.tail.state[threadIdx.x];
   }
-  if (cb == 0 && threadIdx.x >= 64 && threadIdx.x < 128)
-    __hip_atomic_store(pm_flags(mine) + (threadIdx.x - 64), p.tail.state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int NRB>
@@ -819,12 +896,41 @@ __global__ __launch_bounds__(1024) void pipem_step_kernel(DtfPipeMultiArgs m) {
   if (b < d.nC) pm_role_c(m, b);
 }
 
-// One wave in front of the flush launch: returns when every rank's boxes of the last step have arrived
-// (stamps >= the number of steps done).
-__global__ __launch_bounds__(64) void pipem_wait_kernel(DtfPipeMultiArgs m, int nrb) {
-  const int lane = threadIdx.x;
-  const int want = m.b.tail.state[1];
-  pm_flag_wait(m, nrb, want, lane, pm_flag_peek(m, nrb, want, lane));
+// One workgroup in front of the flush launch: returns when every rank's boxes of the last step have arrived (every
+// word of them shows that step's phase).  A wave looks at four 1 KB pieces per request.
+__global__ __launch_bounds__(1024) void pipem_wait_kernel(DtfPipeMultiArgs m, int nrb) {
+  const DtfPipeArgs& p = m.b;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NT = p.HP >> 4;
+  const int last = p.tail.state[1] - 1;               // the run's last step
+  const int phase = pm_phase(last), gen = last & 3;
+  char* const mine = m.region[m.rank];
+  const int per_src = 2 * nrb * NT;                    // D tiles, then output-layer tiles
+  const int total = m.world * per_src;
+  PmPoll st = {0ull, false, false};
+  for (int f0 = wave * 4; f0 < total; f0 += 64) {
+    for (;;) {
+      unsigned stale = 0;
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int f = f0 + u;
+        const bool on = f < total;
+        const int src = on ? f / per_src : 0, r = on ? f - src * per_src : 0;
+        const bool is_d = r < nrb * NT;
+        const int rr = is_d ? r : r - nrb * NT;
+        const int tile = rr / nrb, rb = rr - tile * nrb;
+        const float* base = is_d ? pm_d1(mine, gen, src) + pipe_frag(tile, rb, 0) : pm_p2(mine, gen, src, rb) + (size_t)tile * 256;
+        const rsrc_t rs = make_rsrc(base, 1024u);
+        pm_bld4_sys(rs, on ? (unsigned)lane * 16u : kOOB, 0, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (f0 + u < total) stale |= pm_stale4(v[u], phase);
+      if (pm_poll(m, st, stale, lane) != PM_AGAIN) break;
+    }
+  }
 }
 
 static int pm_nrb_template(int B) {
@@ -916,7 +1022,7 @@ DTF_EXPORT int dtf_pipem_flush(const DtfPipeMultiArgs* a, hipStream_t s) {
   const int rc = pm_validate(a);
   if (rc != DTF_OK) return rc;
   if (!a->b.flush || a->b.prime || a->b.roles != (PIPE_ROLE_W | PIPE_ROLE_F)) return DTF_ERR_ARG;
-  hipLaunchKernelGGL(pipem_wait_kernel, dim3(1), dim3(64), 0, s, *a, pm_nrb_template(a->b.B));
+  hipLaunchKernelGGL(pipem_wait_kernel, dim3(1), dim3(1024), 0, s, *a, pm_nrb_template(a->b.B));
   const int rc2 = dtf_check_launch();
   if (rc2 != DTF_OK) return rc2;
   return pm_launch_any(*a, s);

@@ -6,8 +6,9 @@ back, 318 KB each way per step.  The pipelined step moves, per worker and step, 
 share of the output layer's gradient (28 KB) straight into *boxes* in every rank's HBM - one hop over xGMI, stores
 only - and every rank applies the same sums in the same order to its own replica.
 
-A region (``DTF_PIPEM_REGION_BYTES``, ~4 MB) holds four generations of boxes for up to eight source ranks plus one
-flag (a step stamp) per (source rank, 16-row block).  It is allocated uncached, exported by IPC handle and mapped by
+A region (``DTF_PIPEM_REGION_BYTES``, ~4 MB) holds four generations of boxes for up to eight source ranks; every
+word of a box carries its own arrival mark (lowest mantissa bit = phase of the writing step), so there are no flags
+and a writer never waits for an acknowledgement.  It is allocated uncached, exported by IPC handle and mapped by
 every peer; regions come from (and go back to) the pool of exported regions in ``p2p_allreduce.hip``.
 
 One rank (``world == 1``) needs no process group: the step then exchanges with itself through its own region, which

@@ -36,7 +36,7 @@ stamps = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
 t_ab = torch.zeros(4, dtype=torch.int64, device=dev)
 lib.dtf_set_stamp_buffer_pipem(stamps.data_ptr())
 s = torch.cuda.current_stream().cuda_stream
-names = ["start", "strips in LDS", "D(s-2) term", "flags seen", "z1/h + U rows", "logits", "softmax", "stores acked + flag"]
+names = ["start", "operands + strips in", "D(s-2) term", "boxes of s-1 checked, D(s-1) term", "U rows", "logits", "softmax", "boxes stored"]
 for it in range(6):
     # whole steps, so that the counters advance and every launch finds the flags of the one before
     q = prog.steps_enqueued % prog.P
