@@ -217,7 +217,7 @@ struct DtfMlp2Async {
   int rank, world;
   unsigned timeout_ticks;   // how long a worker that is too far ahead waits for the slowest
   float b1, b2, eps;
-  int* astate;              // the 8 ints of DtfAsyncPushPullArgs.astate; [6], [7]: "the step with this parity pulls whatever
+  int* astate;              // the 16 ints of DtfAsyncPushPullArgs.astate; [6], [7]: "the step with this parity pulls whatever
                             // the period says", written one launch ahead (the launch that reads a slot never writes it)
   int* alog;                // optional [alog_cap][2] ring: {global_step after the push, other workers' updates the replica missed}
   int* applied_snap;        // Adam: [8] local ints, the slices' update counts as launch 1 of the step saw them
@@ -454,8 +454,10 @@ struct DtfAsyncPushPullArgs {
   int optimizer;          // 0 = SGD, 1 = Adam (moments m[], v[] next to the master slices)
   float* m[8];            // Adam moments of slice s in the (mapped) region of its owner
   float* v[8];
-  int* astate;            // optional local ints [8]: [0] global_step at the last pull, [1] own pushes since, [2] forced pulls,
-                          // [3] pushes that had to wait for a slower worker, [4] "pull with the next push", [5] bound given up
+  int* astate;            // optional local ints [16]: [0] global_step at the last pull, [1] own pushes since, [2] forced pulls,
+                          // [3] pushes that had to wait for a slower worker, [4] "pull with the next push", [5] bound given up,
+                          // [6], [7] the same decision per step parity for the push inside the backward launch (DtfMlp2Async),
+                          // [8] workgroups of the running launch that have finished (the last one keeps the books)
   int* alog;              // optional ring [alog_cap][2]: {global_step after the push, updates of OTHER workers the replica missed}
   int alog_cap;
   int pull_every;         // pull on local steps divisible by this (<= 1: every step); other steps push only

@@ -536,7 +536,22 @@ __global__ __launch_bounds__(256) void async_push_pull_kernel(DtfAsyncPushPullAr
     }
     reinterpret_cast<f32x4*>(a.params)[i] = v;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  // The counters are advanced by the workgroup that finishes LAST: every workgroup of this launch has read the
+  // slices' update counts (Adam's bias correction) by then, so a push uses one count throughout, whatever the order in
+  // which its workgroups run.  (Without the bookkeeping words - the start-up check, plain SGD - workgroup 0 does it.)
+  bool keeper = blockIdx.x == 0 && threadIdx.x == 0;
+  if (a.astate) {
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_last = __hip_atomic_fetch_add(a.astate + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+      if (s_last) a.astate[8] = 0;
+    }
+    __syncthreads();
+    keeper = s_last && threadIdx.x == 0;
+  }
+  if (keeper) {
     int gs;
     if (a.mode == 0) {
       gs = __hip_atomic_fetch_add(a.counters[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1;

@@ -123,7 +123,7 @@ class PeerMappedAsyncEngine:
         self.staleness_bound = int(staleness_bound) if int(staleness_bound) >= 0 else None
         # per local step {global_step after the push, updates of other workers the replica had not seen}: device ring
         self.alog = torch.zeros((log_capacity, 2), dtype=torch.int32, device=self.device)
-        self._astate = torch.zeros(8, dtype=torch.int32, device=self.device)
+        self._astate = torch.zeros(16, dtype=torch.int32, device=self.device)
         PeerMappedAsyncEngine._instances += 1
         self._key = f"dtf/async_peer/{PeerMappedAsyncEngine._instances}"
         self.updates_pushed = 0
@@ -329,7 +329,7 @@ class PeerMappedAsyncEngine:
                 own = (lo, lo + self.slice) == tuple(st.shard) and st.m is not None
                 mv[0].copy_(st.m) if own else mv[0].zero_()
                 mv[1].copy_(st.v) if own else mv[1].zero_()
-        self._astate.copy_(torch.tensor([st.global_step(), 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32))
+        self._astate.copy_(torch.tensor([st.global_step()] + [0] * 15, dtype=torch.int32))
         torch.cuda.synchronize(self.device)
         self._barrier()
 
