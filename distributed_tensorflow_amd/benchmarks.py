@@ -383,6 +383,11 @@ def _prepare_graphs(prog, args, graph_steps, device, steps_per_update: int = 1) 
         torch.cuda.synchronize()
 
 
+def _own_wgrad_calls() -> int:
+    from .models.resnet import conv1x1_calls
+    return conv1x1_calls["own_wgrad"]
+
+
 def bench_resnet50_sync(args, rank, world, device):
     from .models.resnet import TorchModuleProgram, resnet50
     from .ops.batchnorm import calls as bn_calls
@@ -429,7 +434,8 @@ def bench_resnet50_sync(args, rank, world, device):
                    "parallelism": f"dp{world} sync_replicas, optimizer state sharded over {world} GPU(s)",
                    "optimizer": optimizer, "mode": "sync", "collective": engine.collective if (world > 1 or force) else "none",
                    "transport": engine.transport, "gradient_buckets": len(prog._groups) if prog._groups else None,
-                   "params": prog.state.layout.used, "convolutions": "MIOpen (library)",
+                   "params": prog.state.layout.used, "convolutions": ("MIOpen (library); weight gradients of the stride-1 1x1 layers: own kernel (conv1x1.hip)"
+                                   if _own_wgrad_calls() else "MIOpen (library)"),
                    "classifier": ("own kernels (MFMA GEMM + fused softmax cross-entropy)"
                                   if head_calls["kernel"] and not head_calls["operators"]
                                   else "PyTorch operators" if not head_calls["kernel"] else "mixed"),

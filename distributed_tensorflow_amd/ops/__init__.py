@@ -1115,3 +1115,47 @@ def gather_cast_transpose(src, rows, dst=None, dst_t=None, m=None):
         M, N, src.stride(0), 0 if dst is None else dst.stride(0), 0 if dst_t is None else dst_t.stride(0), _dtype_code(ref),
         _lib.stream_handle()), "gather_cast_transpose")
     return ref
+
+
+_conv1x1_ws = {}
+
+
+def conv1x1_wgrad(x2d, dy2d, out=None):
+    """Weight gradient of a stride-1 1x1 convolution on channels-last activations (``csrc/kernels/conv1x1.hip``):
+    ``dW[co, ci] = sum_m dy2d[m, co] * x2d[m, ci]`` with ``x2d`` = the input as ``[N*H*W, Cin]`` and ``dy2d`` = the output
+    gradient as ``[N*H*W, Cout]``, both bf16, contiguous.  Returns ``[Cout, Cin]`` bf16 (fp32 accumulation; the
+    reduction is split over workgroups and the partial sums are added in a fixed order).  CPU tensors: the PyTorch
+    statement."""
+    if x2d.dim() != 2 or dy2d.dim() != 2 or x2d.shape[0] != dy2d.shape[0]:
+        raise ValueError("conv1x1_wgrad: x [M, Cin] and dy [M, Cout] with the same M")
+    M, cin = x2d.shape
+    cout = dy2d.shape[1]
+    if not x2d.is_cuda:
+        dw = (dy2d.float().t() @ x2d.float()).to(torch.bfloat16)
+        if out is not None:
+            out.copy_(dw)
+            return out
+        return dw
+    if x2d.dtype != torch.bfloat16 or dy2d.dtype != torch.bfloat16 or not x2d.is_contiguous() or not dy2d.is_contiguous():
+        raise ValueError("conv1x1_wgrad: contiguous bf16 operands")
+    if cin % 8 or cout % 8:
+        raise ValueError("conv1x1_wgrad: channel counts must be multiples of 8")
+    lib = _lib.kernels()
+    if not getattr(lib, "_conv1x1_declared", False):
+        lib.dtf_conv1x1_wgrad_ws_floats.restype = C.c_longlong
+        lib.dtf_conv1x1_wgrad_ws_floats.argtypes = [C.c_longlong, C.c_int, C.c_int]
+        lib.dtf_conv1x1_wgrad.restype = C.c_int
+        lib.dtf_conv1x1_wgrad.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]
+        lib._conv1x1_declared = True
+    need = int(lib.dtf_conv1x1_wgrad_ws_floats(M, cin, cout))
+    key = (x2d.device, torch.cuda.current_stream(x2d.device).cuda_stream)
+    ws = _conv1x1_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _conv1x1_ws[key] = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=x2d.device)   # one per stream
+    if out is None:
+        out = torch.empty((cout, cin), dtype=torch.bfloat16, device=x2d.device)
+    elif out.dtype != torch.bfloat16 or not out.is_contiguous() or out.numel() != cout * cin:
+        raise ValueError("conv1x1_wgrad: out must be contiguous bf16 with Cout * Cin elements")
+    _lib.check(lib.dtf_conv1x1_wgrad(x2d.data_ptr(), dy2d.data_ptr(), ws.data_ptr(), out.data_ptr(), M, cin, cout,
+                                     _lib.stream_handle()), "conv1x1_wgrad")
+    return out

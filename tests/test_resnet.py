@@ -161,3 +161,27 @@ def test_convolution_with_weight_gradient_on_a_second_stream(cin, cout, k, strid
     torch.testing.assert_close(y, yr, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(x.grad, xr.grad, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(w.grad, wr.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_own_1x1_weight_gradient_inside_the_module_step(monkeypatch):
+    """DTF_OWN_CONV1X1_WGRAD=1: the stride-1 1x1 convolutions of the network take their weight gradient from the
+    framework's kernel; the first step's gradients agree with the library's to bf16 rounding."""
+    from distributed_tensorflow_amd.models import resnet as R
+    g = torch.Generator().manual_seed(2)
+    x, y = torch.rand(32, 3, 64, 64, generator=g), torch.randint(0, 10, (32,), generator=g)
+
+    def run(own):
+        monkeypatch.setenv("DTF_OWN_CONV1X1_WGRAD", "1" if own else "0")
+        R.conv1x1_calls["own_wgrad"] = 0
+        torch.manual_seed(0)
+        model = ResNet(layers=(1, 1, 1, 1), num_classes=10, width=16)
+        prog = TorchModuleProgram(model, "cuda:0", x, y, batch=16, optimizer="sgd", lr=0.02, autocast=torch.bfloat16)
+        prog.run(1)
+        torch.cuda.synchronize()
+        return prog.state.grads.clone(), R.conv1x1_calls["own_wgrad"]
+
+    ga, na = run(True)
+    gb, nb = run(False)
+    assert na >= 8 and nb == 0                   # (8 bottleneck 1x1 convolutions + the stride-1 downsample of layer1)
+    assert float((ga - gb).norm() / gb.norm()) < 2e-2

@@ -41,7 +41,7 @@ def timeit(fn, iters):
 
 
 print(f"{'Cin':>5} {'Cout':>5} {'HxW':>4} {'n':>2} | {'lib fwd':>8} {'lib dx':>8} {'lib dw':>8} | {'gemm fwd':>8} {'gemm dx':>8} {'gemm dw':>8} {'(+transp)':>9}")
-tot = [0.0] * 7
+tot = [0.0] * 8
 for cin, cout, hw, cnt in SHAPES:
     M = a.batch * hw * hw
     x = torch.randn(a.batch, hw, hw, cin, device=dev).bfloat16().permute(0, 3, 1, 2)
@@ -61,10 +61,14 @@ for cin, cout, hw, cnt in SHAPES:
     xt, dyt = x2.t().contiguous(), dy2.t().contiguous()
     t_gdw = timeit(lambda: ops.gemm_nt(dyt, xt, dw, epilogue=ops.EPI_WGRAD), a.iters)
     t_tr = timeit(lambda: (x2.t().contiguous(), dy2.t().contiguous()), a.iters)
+    x2c, dy2c = x2.contiguous(), dy2.contiguous()
+    t_own = timeit(lambda: ops.conv1x1_wgrad(x2c, dy2c), a.iters)
+    dw_ref = cb([False, True, False])[1].reshape(cout, cin).float()
+    err_dw = float((ops.conv1x1_wgrad(x2c, dy2c).float() - dw_ref).abs().max() / dw_ref.abs().max())
     ref = F.conv2d(x, w).permute(0, 2, 3, 1).reshape(M, cout).float()
     err = float((y2.float() - ref).abs().max())
-    row = [t_lf, t_ldx, t_ldw, t_gf, t_gdx, t_gdw, t_tr]
+    row = [t_lf, t_ldx, t_ldw, t_gf, t_gdx, t_gdw, t_tr, t_own]
     for i, v in enumerate(row):
         tot[i] += cnt * v
-    print(f"{cin:5d} {cout:5d} {hw:4d} {cnt:2d} | {t_lf:8.1f} {t_ldx:8.1f} {t_ldw:8.1f} | {t_gf:8.1f} {t_gdx:8.1f} {t_gdw:8.1f} {t_tr:9.1f}  err {err:.3f}")
+    print(f"{cin:5d} {cout:5d} {hw:4d} {cnt:2d} | {t_lf:8.1f} {t_ldx:8.1f} {t_ldw:8.1f} | {t_gf:8.1f} {t_gdx:8.1f} {t_gdw:8.1f} {t_tr:9.1f} | own dw {t_own:8.1f} ({2.0 * M * (cin + cout) / t_own / 1e6:5.2f} TB/s, rel err {err_dw:.4f})  err {err:.3f}")
 print("per network (us):", " ".join(f"{v:9.0f}" for v in tot))
