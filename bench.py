@@ -203,16 +203,25 @@ def worker_main(args) -> None:
             sys.stderr.flush()
 
     threading.Thread(target=heartbeat, daemon=True).start()
+    once = threading.Lock()
+
+    def emit(result) -> None:
+        """THE result line, written at most once per process (run_benchmark's watchdog over the untimed follow-up
+        segments writes it from its own thread when they do not come back)."""
+        if once.acquire(blocking=False):
+            os.write(real_stdout, (json.dumps(result) + "\n").encode())
+
+    args._emit = emit
     try:
         from distributed_tensorflow_amd.benchmarks import run_benchmark
         result = run_benchmark(args)
+        if result is not None:
+            emit(result)
     finally:
         done.set()
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         os.close(real_stdout)
-    if result is not None:
-        print(json.dumps(result), flush=True)
 
 
 def main(argv=None) -> int:

@@ -157,6 +157,47 @@ def _steps_to_target(engine, prog, state, batch, per_update, args, rank, world, 
     return out
 
 
+class _FollowUpGuard:
+    """Time limit over the untimed follow-up segments of a multi-worker run (steps to the target loss from a fresh
+    state, the same job in the other update mode).  The headline number exists when they start; if they do not come
+    back within the limit (a peer that stopped answering leaves the others in a collective), rank 0 writes the result
+    line without them and every rank leaves with status 0, instead of the run ending with no line at all.  Every rank
+    arms its timer right after the barrier that closes the timed segment, so they fire together.
+    ``DTF_BENCH_FOLLOWUP_LIMIT_S`` (default 300; 0: no limit)."""
+
+    def __init__(self, args, rank: int, world: int, core: dict):
+        import threading
+        self.limit = float(os.environ.get("DTF_BENCH_FOLLOWUP_LIMIT_S", "300"))
+        self.emit = getattr(args, "_emit", None)
+        self.rank, self.core = rank, core
+        self.timer = None
+        if world > 1 and self.limit > 0 and self.emit is not None:
+            self.timer = threading.Timer(self.limit, self._fire)
+            self.timer.daemon = True
+
+    def _fire(self, why=None):
+        why = why or f"not finished within {self.limit:.0f} s"
+        sys.stderr.write(f"[bench] rank {self.rank}: follow-up segments {why}; reporting the timed segment alone\n")
+        sys.stderr.flush()
+        if self.rank == 0:
+            self.core["follow_up_segments"] = f"{why} (steps_to_target / async_value missing)"
+            self.emit(self.core)
+        os._exit(0)
+
+    def __enter__(self):
+        if self.timer is not None:
+            self.timer.start()
+        return self
+
+    def __exit__(self, etype, evalue, _tb):
+        if self.timer is not None:
+            self.timer.cancel()
+            if etype is not None and issubclass(etype, Exception):
+                # this rank's follow-up failed: the others are left in a collective and leave by their own timers
+                self._fire(f"failed on rank {self.rank} ({etype.__name__}: {evalue})")
+        return False
+
+
 def _time_segment(engine, device, world, steps, graph_steps):
     _sync_all(device, world)
     t0 = time.perf_counter()
@@ -281,28 +322,30 @@ def bench_mlp_sync(args, rank, world, device, wide: bool = False):
     # examples per aggregated update: R gradients of `batch` examples each (distributed.py:92-100)
     value = batch * args.steps * R / dt
     probe = _assert_rccl_world(engine, rank, world, device)
-    target = None
-    if not wide and fast and getattr(args, "target_loss", 0):
-        # steps to the target loss from a fresh state (same seed), same engine settings, outside every clock
-        engine.close_transports()
-        state_t, prog_t, engine_t = build()
-        if selection is not None and engine_t.p2p is not None:
-            engine_t.set_p2p_mode(selection["chosen"])
-        target = _steps_to_target(engine_t, prog_t, state_t, batch, R, args, rank, world, device)
-        engine_t.close_transports()
-    second = None
-    if world > 1 and not wide and fast and not getattr(args, "no_second_mode", False):
-        # the other update mode of the same job, timed the same way, so that one invocation yields both numbers
-        transport = engine.transport
-        dropped = engine.dropped
-        if target is None:
-            engine.close_transports()
-        a2 = _async_args(args)
-        second = bench_mlp_async(a2, rank, world, device)
+    transport, dropped = engine.transport, engine.dropped
+
+    def result(second, target):
         return _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer, dtype_name, R, dt, state, prog,
                             engine, force, last, selection, probe, second, transport, dropped, target)
-    return _sync_result(args, rank, world, device, wide, batch, hidden_units, optimizer, dtype_name, R, dt, state, prog, engine,
-                        force, last, selection, probe, second, engine.transport, engine.dropped, target)
+
+    target = second = None
+    # What follows is outside every clock.  With several workers it runs under a time limit of its own: the timed
+    # segment's result is complete here and is what gets reported if a follow-up segment does not come back.
+    with _FollowUpGuard(args, rank, world, result(None, None)):
+        if not wide and fast and getattr(args, "target_loss", 0):
+            # steps to the target loss from a fresh state (same seed), same engine settings
+            engine.close_transports()
+            state_t, prog_t, engine_t = build()
+            if selection is not None and engine_t.p2p is not None:
+                engine_t.set_p2p_mode(selection["chosen"])
+            target = _steps_to_target(engine_t, prog_t, state_t, batch, R, args, rank, world, device)
+            engine_t.close_transports()
+        if world > 1 and not wide and fast and not getattr(args, "no_second_mode", False):
+            # the other update mode of the same job, timed the same way, so that one invocation yields both numbers
+            if target is None:
+                engine.close_transports()
+            second = bench_mlp_async(_async_args(args), rank, world, device)
+    return result(second, target)
 
 
 def _async_args(args):

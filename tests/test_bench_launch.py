@@ -152,3 +152,14 @@ def test_bench_reports_steps_to_target_loss():
         assert d["examples_to_target"] == d["steps_to_target"] * 100 * d["n_gpus"]
     assert two["steps_to_target"] <= one["steps_to_target"] + 8
     assert two["async_steps_to_target"] > 10 and two["async_examples_to_target"] == two["async_steps_to_target"] * 100
+
+
+def test_a_follow_up_segment_that_does_not_come_back_costs_no_result():
+    """The timed segment's line is written (without steps_to_target / async_value) and the run ends with status 0 when
+    the untimed follow-up segments exceed their limit - here a limit no run can meet."""
+    r = _bench(["--gpus", "2", "--cpu", "--steps", "6", "--warmup", "2"], {"DTF_BENCH_FOLLOWUP_LIMIT_S": "0.0001"})
+    d = _one_json_line(r)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 6
+    assert "not finished" in d["follow_up_segments"]
+    assert "steps_to_target" not in d and "async_value" not in d
+    assert "follow-up segments not finished" in r.stderr
