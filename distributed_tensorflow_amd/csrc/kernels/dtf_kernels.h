@@ -315,7 +315,7 @@ struct DtfPipeMultiArgs {
   int* err;                 // device word: set to 1 when a wait for a peer ran into its limit
   int rank, world;
   unsigned timeout_ticks;   // of the 100 MHz constant clock
-  int pad_;
+  int plain_order;          // 1: workgroup roles in plain block order (several ranks rehearsing on one GPU); 0: XCD-major
 };
 DTF_EXPORT int dtf_pipem_step(const DtfPipeMultiArgs* a, hipStream_t s);
 DTF_EXPORT int dtf_pipem_prime(const DtfPipeMultiArgs* a, hipStream_t s);

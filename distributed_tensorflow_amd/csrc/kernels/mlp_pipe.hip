@@ -46,7 +46,7 @@
 __device__ unsigned long long* pipe_stamp_buf = nullptr;
 #define PIPE_STAMP(slot)                                                                                                       \
   do {                                                                                                                         \
-    if (threadIdx.x == 0 && pipe_stamp_buf) pipe_stamp_buf[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    if (threadIdx.x == 0 && pipe_stamp_buf) pipe_stamp_buf[(size_t)(gridDim.x <= 512 ? dtf_xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 extern "C" __attribute__((visibility("default"))) int dtf_set_stamp_buffer_pipe(unsigned long long* p) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(pipe_stamp_buf), &p, sizeof(p));
@@ -54,7 +54,7 @@ extern "C" __attribute__((visibility("default"))) int dtf_set_stamp_buffer_pipe(
 // shader-clock counter into the same buffer (clock frequency under this load = cycles / elapsed constant-clock time)
 #define PIPE_STAMP_CYCLES(slot)                                                                                      \
   do {                                                                                                               \
-    if (threadIdx.x == 0 && pipe_stamp_buf) pipe_stamp_buf[(size_t)blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+    if (threadIdx.x == 0 && pipe_stamp_buf) pipe_stamp_buf[(size_t)(gridDim.x <= 512 ? dtf_xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) * 8 + (slot)] = __builtin_readcyclecounter(); \
   } while (0)
 #else
 #define PIPE_STAMP(slot) do { } while (0)
@@ -843,24 +843,45 @@ template <int NRB, int TD>
 __global__ __launch_bounds__(1024) void pipe_step_kernel(DtfPipeArgs p) {
   __shared__ float smem[TD == 16 ? PIPE_BIG_SMEM : 9216];
   const PipeDims d = pipe_dims<TD>(p, NRB);
-  int b = blockIdx.x;
+  // Which XCD a workgroup runs on decides what its loads find in that XCD's L2: workgroup i of a launch goes to XCD
+  // i mod 8, and a kernel boundary leaves an L2 with what ITS workgroups read and wrote.  While the whole grid is
+  // resident at once (<= 512 workgroups) the role index is therefore taken XCD-major (blocks 0, 8, 16, ... get indices
+  // 0, 1, 2, ...): the row workgroups - producers and consumers of dz1, the output-layer shares, z1 and W2' from launch
+  // to launch - all sit on XCD 0, the Gram tiles that share batch rows sit together on the next XCDs, and so on.
+  // Measured on the reference shape (2000 steps, one box, us/step): plain block order 6.42; XCD-major with the roles in
+  // the order L G Q W T 5.69, L Q G W T 5.69, L G T W Q 5.70, L T W Q G 6.19, L T G Q W 6.22, L G W Q T 6.25 (the
+  // gather or the weight tiles next to the row workgroups, or all weight tiles on one XCD, cost what the grouping
+  // wins); row workgroups on XCD 0 and everything else dealt round-robin over the other seven 6.10; row workgroups
+  // left spread and only the rest grouped 6.38.  Larger grids run in waves of workgroups; there block order is
+  // dispatch order and the roles with the longest dependent chains go first (256 / 256: 21.1 against 24.5 us).
+  const bool xcd_major = gridDim.x <= 512;
+  int b = xcd_major ? dtf_xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   PIPE_STAMP(0);
-  // launch order = dispatch order: the roles with the longest dependent chains first (the row workgroups, then the
-  // gather with its index -> row hop), the short product tiles last
   if (b < d.nL) {
     if constexpr (TD == 16) pipe_role_l_big<NRB>(p, b, smem);
     else pipe_role_l<NRB>(p, b, smem);
     return;
   }
   b -= d.nL;
-  if (b < d.nT) { pipe_role_t<TD>(p, b); return; }
-  b -= d.nT;
-  if (b < d.nW) { pipe_role_w<NRB, TD>(p, b); return; }
-  b -= d.nW;
-  if (b < d.nQ) { pipe_role_q<NRB, TD>(p, b, smem); return; }
-  b -= d.nQ;
-  if (b < d.nG) { pipe_role_g<NRB, TD>(p, b, smem); return; }
-  b -= d.nG;
+  if (xcd_major) {
+    if (b < d.nG) { pipe_role_g<NRB, TD>(p, b, smem); return; }
+    b -= d.nG;
+    if (b < d.nQ) { pipe_role_q<NRB, TD>(p, b, smem); return; }
+    b -= d.nQ;
+    if (b < d.nW) { pipe_role_w<NRB, TD>(p, b); return; }
+    b -= d.nW;
+    if (b < d.nT) { pipe_role_t<TD>(p, b); return; }
+    b -= d.nT;
+  } else {
+    if (b < d.nT) { pipe_role_t<TD>(p, b); return; }
+    b -= d.nT;
+    if (b < d.nW) { pipe_role_w<NRB, TD>(p, b); return; }
+    b -= d.nW;
+    if (b < d.nQ) { pipe_role_q<NRB, TD>(p, b, smem); return; }
+    b -= d.nQ;
+    if (b < d.nG) { pipe_role_g<NRB, TD>(p, b, smem); return; }
+    b -= d.nG;
+  }
   if (b < d.nF) { pipe_role_f<NRB, TD>(p); return; }
   b -= d.nF;
   if (b < d.nC) pipe_role_c<TD>(p, b);

@@ -49,12 +49,12 @@
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 
-// Diagnostic build only (-DDTF_STAMPS): per-workgroup timestamps of the 100 MHz constant clock.
+// Diagnostic build only (-DDTF_STAMPS): timestamps of the 100 MHz constant clock per row workgroup (index rbl).
 #ifdef DTF_STAMPS
 __device__ unsigned long long* pipem_stamp_buf = nullptr;
 #define PM_STAMP(slot)                                                                                                           \
   do {                                                                                                                           \
-    if (threadIdx.x == 0 && pipem_stamp_buf) pipem_stamp_buf[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    if (threadIdx.x == 0 && pipem_stamp_buf) pipem_stamp_buf[(size_t)rbl * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 extern "C" __attribute__((visibility("default"))) int dtf_set_stamp_buffer_pipem(unsigned long long* p) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(pipem_stamp_buf), &p, sizeof(p));
@@ -880,17 +880,32 @@ template <int NRB>
 __global__ __launch_bounds__(1024) void pipem_step_kernel(DtfPipeMultiArgs m) {
   extern __shared__ __attribute__((aligned(16))) float pm_smem[];
   const PmDims d = pm_dims(m, NRB);
-  int b = blockIdx.x;
+  // role index XCD-major with the roles in the order L G Q W T while the grid is resident at once, as in
+  // pipe_step_kernel (mlp_pipe.hip), where it is measured; plain_order: several ranks rehearse on ONE GPU, where the
+  // row workgroups of all of them would crowd XCD 0
+  const bool xcd_major = gridDim.x <= 512 && !m.plain_order;
+  int b = xcd_major ? dtf_xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   if (b < d.nL) { pm_role_l<NRB>(m, b, pm_smem); return; }
   b -= d.nL;
-  if (b < d.nT) { pm_role_t(m, b); return; }
-  b -= d.nT;
-  if (b < d.nW) { pm_role_w<NRB>(m, b, pm_smem, d.ks); return; }
-  b -= d.nW;
-  if (b < d.nQ) { pm_role_q<NRB>(m, b, pm_smem); return; }
-  b -= d.nQ;
-  if (b < d.nG) { pm_role_g<NRB>(m, b, pm_smem); return; }
-  b -= d.nG;
+  if (xcd_major) {
+    if (b < d.nG) { pm_role_g<NRB>(m, b, pm_smem); return; }
+    b -= d.nG;
+    if (b < d.nQ) { pm_role_q<NRB>(m, b, pm_smem); return; }
+    b -= d.nQ;
+    if (b < d.nW) { pm_role_w<NRB>(m, b, pm_smem, d.ks); return; }
+    b -= d.nW;
+    if (b < d.nT) { pm_role_t(m, b); return; }
+    b -= d.nT;
+  } else {
+    if (b < d.nT) { pm_role_t(m, b); return; }
+    b -= d.nT;
+    if (b < d.nW) { pm_role_w<NRB>(m, b, pm_smem, d.ks); return; }
+    b -= d.nW;
+    if (b < d.nQ) { pm_role_q<NRB>(m, b, pm_smem); return; }
+    b -= d.nQ;
+    if (b < d.nG) { pm_role_g<NRB>(m, b, pm_smem); return; }
+    b -= d.nG;
+  }
   if (b < d.nF) { pm_role_f<NRB>(m); return; }
   b -= d.nF;
   if (b < d.nC) pm_role_c(m, b);

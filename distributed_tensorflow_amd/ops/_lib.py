@@ -163,7 +163,7 @@ class PipeArgs(C.Structure):
 class PipeMultiArgs(C.Structure):
     """Mirror of ``DtfPipeMultiArgs``: the one-launch pipelined step of N synchronous workers (mlp_pipe_multi.hip)."""
     _fields_ = [("b", PipeArgs), ("region", C.c_void_p * 8), ("perm", C.c_void_p * 8), ("err", C.c_void_p),
-                ("rank", C.c_int), ("world", C.c_int), ("timeout_ticks", C.c_uint), ("pad_", C.c_int)]
+                ("rank", C.c_int), ("world", C.c_int), ("timeout_ticks", C.c_uint), ("plain_order", C.c_int)]
 
 
 PIPE_ROLE_L, PIPE_ROLE_Q, PIPE_ROLE_G, PIPE_ROLE_W, PIPE_ROLE_T, PIPE_ROLE_F, PIPE_ROLE_C = 1, 2, 4, 8, 16, 32, 64

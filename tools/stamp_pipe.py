@@ -29,8 +29,9 @@ stamps = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
 t_ab = torch.zeros(4, dtype=torch.int64, device=dev)
 lib.dtf_set_stamp_buffer_pipe(stamps.data_ptr())
 s = torch.cuda.current_stream().cuda_stream
-# grid order: L (14), T (13), W (22), Q (49), G (126)
-ranges = [("L", 0, 14), ("T", 14, 27), ("W", 27, 49), ("Q", 49, 98), ("G", 98, 224)]
+# role order (stamps are indexed by role index, not by block): L (14), G (98), Q (49), W (22), T (13)
+ranges = [("L", 0, 14), ("G", 14, 112), ("Q", 112, 161), ("W", 161, 183), ("T", 183, 196)]
+T_LO, T_HI = 183, 196
 
 
 def show(tag, rel, lo, hi):
@@ -51,12 +52,12 @@ for it in range(6):
     sv = stamps.cpu().numpy().reshape(nwg, 8).astype(np.int64)
     t0, t1 = int(t_ab[0]), int(t_ab[1])
     rel = np.where(sv > 0, (sv - t0) * 10, 0)
-    rel[14:27, 2:4] = 0
+    rel[T_LO:T_HI, 2:4] = 0
     print(f"launch {it}: stamp->stamp {(t1 - t0) * 10} ns   (L: s0 start, s1 loads issued, s2 stage-1 MFMAs done, s3 barrier, s4 h tiles,"
           " s5 logits, s6 softmax, s7 end; Q/W: s1 MFMAs done; T: s1 row index known)")
     for tag, lo, hi in ranges:
         show(tag, rel, lo, hi)
-    tw = sv[14:27]      # role T: slots 0/1 constant clock at start/end, slots 2/3 shader cycle counter at start/end
+    tw = sv[T_LO:T_HI]      # role T: slots 0/1 constant clock at start/end, slots 2/3 shader cycle counter at start/end
     ok = (tw[:, 1] > tw[:, 0]) & (tw[:, 3] > tw[:, 2])
     if ok.any():
         ghz = (tw[ok, 3] - tw[ok, 2]) / ((tw[ok, 1] - tw[ok, 0]) * 10.0)
