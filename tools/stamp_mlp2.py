@@ -86,7 +86,8 @@ for which in ("fwd", "bwd"):
         if which == "fwd":
             show("tiles", rel, slice(0, 91))
         else:
-            show("stat", rel, slice(0, 13))
-            show("dW1", rel, slice(13, 13 + 86))
-            show("dW2", rel, slice(99, 101))
+            # stamps are indexed by role index: dW1 | dW2 | stat | tail
+            show("dW1", rel, slice(0, 86))
+            show("dW2", rel, slice(86, 88))
+            show("stat", rel, slice(88, 101))
             show("tail", rel, slice(101, 114))
