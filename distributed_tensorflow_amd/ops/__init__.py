@@ -733,7 +733,9 @@ def build_pipem_args(x, labels, bufs, ridx, w1, b1, w2, b2, wlog, batch, rows_to
     out = _lib.PipeMultiArgs(b=base, err=err.data_ptr(), rank=rank, world=world,
                              timeout_ticks=int(min(4.0e9, max(1.0, timeout_s * 1e8))),
                              # ranks that share one GPU (rehearsals) would all put their row workgroups on XCD 0
-                             plain_order=1 if (world > 1 and os.environ.get("DTF_SHARE_GPU") == "1") else 0)
+                             # (DTF_PIPEM_PLAIN_ORDER=1: plain block order everywhere, for comparison)
+                             plain_order=1 if ((world > 1 and os.environ.get("DTF_SHARE_GPU") == "1")
+                                               or os.environ.get("DTF_PIPEM_PLAIN_ORDER") == "1") else 0)
     for r in range(world):
         out.region[r] = regions[r]
         out.perm[r] = None if perms[r] is None else perms[r].data_ptr()
